@@ -1,0 +1,163 @@
+/*
+ * ytvln.h -- C ABI of libytvln.so: the MI355X (gfx950 / CDNA4) kernels behind the ViLBERT hot path of
+ * JeremyLinky/YouTube-VLN (forward/backward of vilbert/vilbert.py, the losses of utils/utils_init.py:108-164 and
+ * the AdamW step of vilbert/optimization.py:141-187).
+ *
+ * The reference has no FFI layer of its own: its "plugin API" for this path is the Python class surface of
+ * vilbert.vilbert / lily.  Each entry point below therefore cites the reference code whose
+ * arithmetic it replaces; the Python modules in youtube-vln_amd/ytvln keep the reference class / argument names and
+ * call these through ctypes (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch allocator);
+ *     the library never allocates, frees or synchronises;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - row-major fp32 unless stated; `ld*` are leading dimensions in ELEMENTS;
+ *   - return value 0 = launched, negative = rejected (bad argument / launch failure); ytvln_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI;
+ *   - dropout: Philox4x32-10 keyed by (rng[0] = seed, rng[1] = forward counter) read from DEVICE memory (graph-replay
+ *     safe) and by a host-side `site` id; the backward pass regenerates the identical mask from the same triple.
+ */
+#ifndef YTVLN_H
+#define YTVLN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YTVLN_ABI_VERSION 1
+
+int ytvln_version(void);
+const char* ytvln_last_error(void);
+
+/* activation / epilogue selectors for ytvln_gemm_f32 */
+enum {
+    YTVLN_EPI_NONE = 0,       /* C = A.B (+bias)                                                             */
+    YTVLN_EPI_GELU = 1,       /* aux = A.B + bias (pre-activation, optional) ; C = gelu_erf(aux)  vilbert.py:119 */
+    YTVLN_EPI_RELU = 2,       /* C = max(A.B + bias, 0)                                            vilbert.py:832 */
+    YTVLN_EPI_MUL_DGELU = 3,  /* C = (A.B) * gelu'(aux)      backward of EPI_GELU through the next Linear        */
+    YTVLN_EPI_MUL_DRELU = 4   /* C = (A.B) * (aux > 0)       backward of EPI_RELU (aux = the forward output)     */
+};
+
+/* Dense projection on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).  Replaces every nn.Linear / F.linear on the path
+ * (vilbert.py:285-287, 322, 352, 365, 555-568, 641-644, 831, 864, 906, 968, 1358 ...) and their autograd backward.
+ *   C[M,N] (+)= op(A)[M,K] . op(B)[K,N]
+ *   transA = 0: A stored [M,K] (lda >= K)      transA = 1: A stored [K,M] (lda >= M)
+ *   transB = 0: B stored [K,N] (ldb >= N)      transB = 1: B stored [N,K] (ldb >= K)   <- nn.Linear weight layout
+ *   bias: [N] or NULL.  beta: 0 = overwrite, 1 = accumulate into C.  aux/ldaux: see the epilogue enum (may be NULL). */
+int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                   int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
+                   float beta, void* stream);
+
+/* out[b, n] = sum over the b-th block of `rows_per_block` rows of x[:, n].  out is [ceil(M/rows_per_block), N] with
+ * leading dimension ldo (bias gradients, position-embedding gradient, second stage of every column reduction). */
+int ytvln_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, int64_t ldo, int rows_per_block,
+                     void* stream);
+
+/* out[b, k, n] = sum over rows r of block b with idx[r] == k of x[r, n], for small tables (KT <= 32): gradient of
+ * image_sequence_embeddings (vilbert.py:1364) and token_type_embeddings (:251).  idx_f32 (float indices, as stored in
+ * image_loc[..., 11]) or idx_i64 is used, whichever is non-NULL. */
+int ytvln_colsum_by_index_f32(const float* x, int64_t ldx, const float* idx_f32, int64_t idx_stride,
+                              const int64_t* idx_i64, int M, int N, int KT, float* out, int rows_per_block,
+                              void* stream);
+
+/* table_grad[idx[r], :] += x[r, :] (atomic), rows with idx == skip_idx ignored: backward of nn.Embedding with
+ * padding_idx (vilbert.py:225-227, 249). */
+int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int M, int H, float* table_grad,
+                               int64_t skip_idx, void* stream);
+
+/* Fused (dropout ->) residual add -> LayerNorm (-> dropout).  BertLayerNorm, vilbert.py:213-217 (biased variance, eps
+ * inside the sqrt) together with the dropout/add that always precedes it (:322-324, :365-367, :641-648) or follows it
+ * (:254-255, :1367-1368).
+ *   s = (p_pre > 0 ? dropout(x) : x) + (res ? res : 0);  y = gamma * (s - mean) * rstd + beta;  p_post: y = dropout(y)
+ * s_out receives s (may alias x; may be NULL when not training), mean/rstd are [rows] (may be NULL). */
+int ytvln_ln_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y, float* s_out,
+                     float* mean, float* rstd, int64_t rows, int H, float eps, float p_pre, float p_post,
+                     const int64_t* rng, int64_t site, void* stream);
+
+/* Backward of the above.  ds = dL/ds (gradient w.r.t. the residual input), dx = gradient w.r.t. x (written only when
+ * p_pre > 0; otherwise dx == ds and dx may be NULL).  partial is [nblocks, 2, H] (dgamma then dbeta partial sums, to be
+ * reduced with ytvln_colsum_f32); nblocks = ytvln_ln_bwd_blocks(rows). */
+int ytvln_ln_bwd_blocks(int64_t rows);
+int ytvln_ln_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                     float* ds, float* dx, float* partial, int64_t rows, int H, float p_pre, float p_post,
+                     const int64_t* rng, int64_t site, void* stream);
+
+/* BertEmbeddings.forward, vilbert.py:240-256: s = word[ids] + pos[t] + type[tt]; y = dropout(LN(s)). rows = N*T. */
+int ytvln_text_embed_fwd_f32(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos,
+                             const float* type, const float* gamma, const float* beta, float* y, float* s_out,
+                             float* mean, float* rstd, int64_t rows, int T, int H, float eps, float p_post,
+                             const int64_t* rng, int64_t site, void* stream);
+
+/* BertImageEmbeddings.forward after the 2048->Hv projection, vilbert.py:1361-1368:
+ *   s = img + W5.loc[0:5] + b5 + W4.loc[5:9] + b4 + W2.loc[9:11] + b2 + E32[(int)loc[11]];  y = dropout(LN(s))
+ * img is [rows,H] (already contains its own bias), loc is [rows,12]; W5 [H,5], W4 [H,4], W2 [H,2], E [32,H]. */
+int ytvln_image_embed_fwd_f32(const float* img, const float* loc, const float* W5, const float* b5, const float* W4,
+                              const float* b4, const float* W2, const float* b2, const float* E, const float* gamma,
+                              const float* beta, float* y, float* s_out, float* mean, float* rstd, int64_t rows,
+                              int H, float eps, float p_post, const int64_t* rng, int64_t site, void* stream);
+
+/* dz = dy * act'(aux) elementwise (act = YTVLN_EPI_GELU: aux is the pre-activation; YTVLN_EPI_RELU: aux is the output). */
+int ytvln_act_bwd_f32(const float* dy, const float* aux, float* dz, int64_t n, int act, void* stream);
+
+/* y = x * keep / (1 - p): nn.Dropout forward and (applied to dy) backward (lily.py:100). */
+int ytvln_dropout_f32(const float* x, float* y, int64_t n, float p, const int64_t* rng, int64_t site, void* stream);
+
+/* Fused multi-head attention on the fp32 matrix cores, flash-style (scores never reach HBM).  One entry point serves
+ * BertSelfAttention (vilbert.py:284-311), BertImageSelfAttention (:413-440) and both directions of BertBiAttention
+ * (:577-616):   ctx[n, i, h*d:(h+1)*d] = softmax_j(q_i.k_j * scale + mask[n, j]) (dropout) . v_j
+ *   q: rows n*Tq+i, head h at columns h*d.., leading dimension ldq (so packed QKV projections are consumed in place);
+ *   k, v likewise with Tk rows per n; mask: additive [N, Tk] (0 / -10000, vilbert.py:1282,1287) or NULL;
+ *   lse [N, heads, Tq] receives log-sum-exp of the scaled+masked scores (saved for backward).  d in {32, 64, 128}. */
+int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                       const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                       int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream);
+
+/* Backward: delta [N,heads,Tq] is scratch (row sums of dctx*ctx).  dq/dk/dv use the same strided layout as q/k/v and
+ * are overwritten. */
+int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                       const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
+                       float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, int N,
+                       int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng, int64_t site,
+                       void* stream);
+
+/* probs[n,h,i,j] = exp(q_i.k_j*scale + mask - lse): the attention_probs tensor the reference returns when
+ * output_all_attention_masks=True (vilbert.py:300, 311).  Diagnostic path, not on the training step. */
+int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,
+                         float* probs, int N, int heads, int Tq, int Tk, int d, float scale, void* stream);
+
+/* F.cross_entropy(logits, target, ignore_index) (utils_init.py:133-135, 141) -- also with -inf padded logits.
+ * fwd: row_lse [M], out[0] = mean loss over non-ignored rows (NaN when none, like the reference), out[1] = their count.
+ * bwd: dlogits = (softmax - onehot) * gout[0] / count for valid rows, 0 otherwise. */
+int ytvln_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, float* row_lse,
+                     float* row_loss, float* out, int M, int V, void* stream);
+int ytvln_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
+                     const float* out, const float* gout, float* dlogits, int64_t ldd, int M, int V, void* stream);
+
+/* Masked KL of utils_init.py:117-128: sum_rows mask * sum_c t*(log t - log_softmax(pred)) / max(1, sum mask). */
+int ytvln_kl_fwd_f32(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask,
+                     float* row_lse, float* row_loss, float* out, int M, int C, void* stream);
+int ytvln_kl_bwd_f32(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask,
+                     const float* row_lse, const float* out, const float* gout, float* dpred, int64_t ldd, int M,
+                     int C, void* stream);
+
+/* F.binary_cross_entropy_with_logits(x, t, pos_weight) with mean reduction (utils_init.py:143, 160-161). n <= 65536.
+ * pos_weight is a DEVICE scalar or NULL.  bwd writes dx. */
+int ytvln_bce_fwd_f32(const float* x, const float* t, const float* pos_weight, float* out, int n, void* stream);
+int ytvln_bce_bwd_f32(const float* x, const float* t, const float* pos_weight, const float* gout, float* dx, int n,
+                      void* stream);
+
+/* Fused AdamW of vilbert/optimization.py:141-187 over flat arenas.  chunks is a DEVICE array of nchunks records
+ * {int64 offset, int64 length, float weight_decay, float pad} (24 bytes); hyper is a DEVICE array
+ * {beta1, beta2, eps, step_size = lr*sqrt(1-b2^t)/(1-b1^t), lr} of floats (updated by the host per step; graph-safe).
+ *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= step_size * m/(sqrt(v)+eps);  p -= lr*wd*p   (decay after update)
+ * grad_scale multiplies g on the fly (1/world_size after a summed all-reduce). */
+int ytvln_adamw_f32(float* p, const float* g, float* m, float* v, const void* chunks, int nchunks, const float* hyper,
+                    float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YTVLN_H */

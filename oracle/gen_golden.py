@@ -1,0 +1,430 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference) on seeded inputs.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container only (the reference cannot travel).  Usage:
+
+    python oracle/gen_golden.py [g0 g1 g2 g3 g4 g5 schema]
+
+For every case the same inputs are also pushed through the oracle restatement (`oracle/vilbert_ref.py`) and the
+script aborts if they disagree, so a committed fixture certifies: reference == oracle == (later, on the GPU) HIP path.
+Inputs and weights come from `ytvln.synth` (numpy RandomState recipes) and are therefore re-creatable on the GPU box;
+small cases also store them verbatim.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "youtube-vln_amd"))
+
+import ref_import  # noqa: E402
+import vilbert_ref as O  # noqa: E402
+from ytvln import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CFG_DIR = os.path.join(ROOT, "youtube-vln_amd", "configs")
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+ZERO_DROP = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0,
+                 v_hidden_dropout_prob=0.0)
+
+
+def load_cfg(R, name, **over):
+    d = json.load(open(os.path.join(CFG_DIR, name)))
+    d.update(over)
+    return R.vilbert.BertConfig(**d), O.RefConfig(**d)
+
+
+def ref_args(**kw):
+    a = dict(model_name="vilbert", ranking=False, traj_judge=False, masked_vision=False, masked_language=False,
+             pretrain=True, num_negatives=2, traj_loss_scale=1.0, not_traj_judge_data=False, local_rank=-1,
+             skip_all_reduce=True, weight_decay=0.01, learning_rate=4e-5, no_scheduler=False, ConstantLR=False,
+             gradient_accumulation_steps=1, num_epochs=1, warmup_proportion=0.2, cooldown_factor=2.0, resume=False)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+def flags_of(args):
+    return O.TaskFlags(ranking=args.ranking, traj_judge=args.traj_judge, masked_vision=args.masked_vision,
+                       masked_language=args.masked_language, pretrain=args.pretrain, num_negatives=args.num_negatives,
+                       traj_loss_scale=args.traj_loss_scale, not_traj_judge_data=args.not_traj_judge_data)
+
+
+def build_lily(R, rcfg, args, seed):
+    rcfg.args = args
+    model = R.lily.Lily(rcfg, dropout_prob=0.0)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    W = synth.make_weights(shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    return model, W, shapes
+
+
+def state_of(W):
+    return {k: torch.from_numpy(v).clone() for k, v in W.items()}
+
+
+def check(name, a, b, atol=2e-5, rtol=2e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    ok = torch.allclose(a, b, atol=atol, rtol=rtol, equal_nan=True)
+    if not ok:
+        raise SystemExit(f"ORACLE != REFERENCE at {name}: max abs err {err:.3e}")
+    return err
+
+
+def ref_losses(R, batch, outputs, args, training=True):
+    out = {}
+    total = torch.tensor(0.0)
+    for task, flag in O.TASK_ORDER:
+        if getattr(args, flag):
+            _, _, l, c = R.utils_init.get_loss_correct(batch, outputs, task, args, None, training)
+            out[task] = l
+            out["correct_" + task] = c
+            total = total + (args.traj_loss_scale * l if task == "traj" else l)
+    return total, out
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+def g0(R):
+    """micro config, everything recorded: intermediates, probs, logits, losses, all grads, 3 AdamW steps."""
+    rcfg, ocfg = load_cfg(R, "micro.json", **ZERO_DROP)
+    args = ref_args(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    model, W, shapes = build_lily(R, rcfg, args, seed=11)
+    nb = synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, opt_holes=1,
+                          ignore_rank_frac=0.0)
+    batch = synth.to_torch(nb)
+    out = {"in_%02d" % i: a for i, a in enumerate(nb)}
+    out.update({"w/" + k: v for k, v in W.items()})
+
+    # forward with hooks for intermediates
+    model.eval()
+    inter = {}
+    hooks = []
+
+    def hook(name):
+        def f(mod, inp, outp):
+            inter[name] = outp
+        return f
+
+    hooks.append(model.bert.embeddings.register_forward_hook(hook("embedding_output")))
+    hooks.append(model.bert.v_embeddings.register_forward_hook(hook("v_embedding_output")))
+    for i, l in enumerate(model.bert.encoder.layer):
+        hooks.append(l.register_forward_hook(hook(f"t{i}")))
+    for i, l in enumerate(model.bert.encoder.v_layer):
+        hooks.append(l.register_forward_hook(hook(f"v{i}")))
+    for i, l in enumerate(model.bert.encoder.c_layer):
+        hooks.append(l.register_forward_hook(hook(f"c{i}")))
+    inputs = R.utils_init.get_model_input(batch)
+    with torch.no_grad():
+        outputs = model(*inputs)
+        total, per = ref_losses(R, batch, outputs, args)
+    for h in hooks:
+        h.remove()
+    col = {}
+    S = state_of(W)
+    ids, feat, loc, seg, imask, vmask = O.model_input(batch)
+    with torch.no_grad():
+        oo = O.lily_forward(S, ocfg, flags_of(args), ids, feat, loc, seg, imask, vmask, collect=col)
+        ototal, oper = O.total_loss(batch, oo, flags_of(args))
+    out["embedding_output"] = np_(inter["embedding_output"])
+    out["v_embedding_output"] = np_(inter["v_embedding_output"])
+    check("emb", inter["embedding_output"], col["embedding_output"])
+    check("vemb", inter["v_embedding_output"], col["v_embedding_output"])
+    for name, val in inter.items():
+        if name[0] == "t" and name[1:].isdigit():
+            out[name + ".t"], out[name + ".probs"] = np_(val[0]), np_(val[1])
+            check(name, val[0], col[name + ".t"]); check(name + "p", val[1], col[name + ".probs"])
+        elif name[0] == "v" and name[1:].isdigit():
+            out[name + ".v"], out[name + ".probs"] = np_(val[0]), np_(val[1])
+            check(name, val[0], col[name + ".v"]); check(name + "p", val[1], col[name + ".probs"])
+        elif name[0] == "c":
+            out[name + ".v"], out[name + ".t"] = np_(val[0]), np_(val[1])
+            out[name + ".probs1"], out[name + ".probs2"] = np_(val[2][0]), np_(val[2][1])
+            check(name, val[0], col[name + ".v"]); check(name, val[1], col[name + ".t"])
+            check(name, val[2][0], col[name + ".probs"][0]); check(name, val[2][1], col[name + ".probs"][1])
+    for k, v in outputs.items():
+        out["logits/" + k] = np_(v)
+        check("logits/" + k, v, oo[k])
+    for k, v in per.items():
+        out["loss/" + k] = np_(v)
+        if not k.startswith("correct_"):
+            check("loss/" + k, v, oper[k], 1e-6, 1e-6)
+    out["loss/total"] = np_(total)
+    check("total", total, ototal, 1e-6, 1e-6)
+
+    # three training steps with the reference optimizer + schedule (lr: 0, lr/2, lr ... warm-up from zero)
+    model.train()
+    args.learning_rate = 1e-3
+    opt, sched, _, _ = R.vilbert_init.get_optimization(args, model, 10, None)
+    ost = O.AdamWState()
+    warm, tot = O.schedule_totals(10, 1, 1)
+    for step in range(3):
+        outputs = model(*R.utils_init.get_model_input(batch))
+        total, per = ref_losses(R, batch, outputs, args)
+        total.backward()
+        if step == 0:
+            for n, p in model.named_parameters():
+                out["grad/" + n] = np_(p.grad) if p.grad is not None else np.zeros(0, np.float32)
+            out["unused"] = np.array([n for n, p in model.named_parameters() if p.grad is None])
+        lr_now = sched.get_last_lr()[0]
+        oloss, _, ograds, _ = O.train_step(S, ocfg, flags_of(args), batch, ost, args.learning_rate * O.warmup_linear(step, warm, tot))
+        check(f"step{step}.loss", total, oloss, 1e-6, 1e-6)
+        if step == 0:
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    assert ograds[n] is None, n
+                else:
+                    check("grad/" + n, p.grad, ograds[n], 1e-6, 1e-4)
+        out[f"step{step}.loss"], out[f"step{step}.lr"] = np_(total), np.float64(lr_now)
+        assert abs(lr_now - args.learning_rate * O.warmup_linear(step, warm, tot)) < 1e-12
+        opt.step(); sched.step(); model.zero_grad()
+        for n, p in model.named_parameters():
+            check(f"step{step}.param/" + n, p, S[n], 1e-7, 1e-6)
+    for n, p in model.named_parameters():
+        out["after3/" + n] = np_(p)
+        if p in opt.state and len(opt.state[p]):
+            out["exp_avg/" + n] = np_(opt.state[p]["exp_avg"])
+            out["exp_avg_sq/" + n] = np_(opt.state[p]["exp_avg_sq"])
+    np.savez_compressed(os.path.join(GOLD, "g0_micro.npz"), **out)
+    print("g0 ok: unused params =", len(out["unused"]))
+
+
+def _summaries(R, model, batch, args, ocfg, W, out, lr=4e-5, slices=64):
+    """Losses, logit slices, per-tensor grad norms and post-step checksums (one AdamW step, constant lr)."""
+    model.train()
+    outputs = model(*R.utils_init.get_model_input(batch))
+    total, per = ref_losses(R, batch, outputs, args)
+    total.backward()
+    S = state_of(W)
+    ost = O.AdamWState()
+    oloss, oper, ograds, oo = O.train_step(S, ocfg, flags_of(args), batch, ost, lr)
+    check("total", total, oloss, 2e-6, 2e-6)
+    for k, v in outputs.items():
+        check("logits/" + k, v, oo[k], 5e-5, 5e-5)
+        flat = v.detach().reshape(v.shape[0], -1)
+        out["logits/" + k] = np_(v) if v.numel() <= 4096 else np_(flat[:, :: max(1, flat.shape[1] // slices)][:, :slices])
+        out["logits_stride/" + k] = np.int64(1 if v.numel() <= 4096 else max(1, flat.shape[1] // slices))
+        out["logits_sum/" + k] = np.float64(v.double().sum().item())
+        out["logits_abssum/" + k] = np.float64(v.double().abs().sum().item())
+    for k, v in per.items():
+        out["loss/" + k] = np_(v)
+    out["loss/total"] = np_(total)
+    names, gn, unused = [], [], []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            unused.append(n)
+            assert ograds[n] is None, n
+            continue
+        names.append(n)
+        gn.append(p.grad.double().norm().item())
+        rel = (p.grad.double() - ograds[n].double()).norm().item() / max(gn[-1], 1e-30)
+        if rel > 2e-4 and gn[-1] > 1e-9:
+            raise SystemExit(f"grad mismatch {n}: rel {rel:.2e}")
+    out["grad_names"], out["grad_norms"], out["unused"] = np.array(names), np.array(gn), np.array(unused)
+    opt = R.optimization.AdamW([{"params": [p for n, p in model.named_parameters() if not O.decays(n)], "weight_decay": 0.0},
+                                {"params": [p for n, p in model.named_parameters() if O.decays(n)], "weight_decay": 0.01}], lr=lr)
+    opt.step()
+    psum, pnorm = [], []
+    for n, p in model.named_parameters():
+        check("post/" + n, p, S[n], 1e-7, 1e-6)
+        psum.append(p.double().sum().item()); pnorm.append(p.double().norm().item())
+    out["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    out["post_sum"], out["post_norm"] = np.array(psum), np.array(pnorm)
+    out["lr"] = np.float64(lr)
+
+
+def g1(R):
+    """BASELINE config 1: tiny 2+2+1, hidden 256, bs=2, K=7, T=16, R=8, masked language only."""
+    rcfg, ocfg = load_cfg(R, "tiny_2_2_1.json", **ZERO_DROP)
+    args = ref_args(masked_language=True)
+    model, W, _ = build_lily(R, rcfg, args, seed=12)
+    nb = synth.make_batch(bs=2, K=7, T=16, frames=1, boxes=8, seed=22)
+    out = {}
+    _summaries(R, model, synth.to_torch(nb), args, ocfg, W, out)
+    np.savez_compressed(os.path.join(GOLD, "g1_tiny_mlm.npz"), **out)
+    print("g1 ok", {k: float(v) for k, v in out.items() if k.startswith("loss/")})
+
+
+def g2(R):
+    """BASELINE config 2 shapes at N=7: full 12/6/6 model, T=80, R=8x36=288, all four losses."""
+    rcfg, ocfg = load_cfg(R, "bert_base_6_layer_6_connect.json", **ZERO_DROP)
+    args = ref_args(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    model, W, _ = build_lily(R, rcfg, args, seed=13)
+    nb = synth.make_batch(bs=1, K=7, T=80, frames=8, boxes=36, seed=23, ignore_rank_frac=0.0)
+    out = {}
+    _summaries(R, model, synth.to_torch(nb), args, ocfg, W, out)
+    np.savez_compressed(os.path.join(GOLD, "g2_full_n7.npz"), **out)
+    print("g2 ok", {k: float(v) for k, v in out.items() if k.startswith("loss/")})
+
+
+def g3(R):
+    """BertForMultiModalPreTraining (vilbert.py:1373-1455) on the tiny config: loss mode and prediction mode."""
+    rcfg, ocfg = load_cfg(R, "tiny_2_2_1.json", **ZERO_DROP)
+    model = R.vilbert.BertForMultiModalPreTraining(rcfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    W = synth.make_weights(shapes, 14)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    model.eval()
+    nb = synth.make_batch(bs=3, K=1, T=12, frames=2, boxes=5, seed=24)
+    b = synth.to_torch(nb)
+    ids, feat, loc, vmask = b[6][:, 0], b[1][:, 0], b[2][:, 0], b[3][:, 0]
+    imask, labels = b[7][:, 0], b[8][:, 0]
+    img_label, img_target = b[5][:, 0, 1:], b[4][:, 0, 1:]
+    nsl = torch.tensor([0, 1, 0])
+    S = state_of(W)
+    with torch.no_grad():
+        l = model(ids, feat, loc, None, imask, vmask, labels, img_label, img_target, nsl)
+        p = model(ids, feat, loc, None, imask, vmask)
+        ol = O.multimodal_pretraining_forward(S, ocfg, ids, feat, loc, None, imask, vmask, labels, img_label, img_target, nsl)
+        op = O.multimodal_pretraining_forward(S, ocfg, ids, feat, loc, None, imask, vmask)
+    out = {}
+    for i, n in enumerate(("masked_lm_loss", "masked_img_loss", "next_sentence_loss")):
+        out[n] = np_(l[i]); check(n, l[i], ol[i], 1e-6, 1e-6)
+    for i, n in enumerate(("prediction_scores_t", "prediction_scores_v", "seq_relationship_score")):
+        check(n, p[i], op[i], 5e-5, 5e-5)
+        out[n] = np_(p[i]) if p[i].numel() < 8192 else np_(p[i].reshape(p[i].shape[0], -1)[:, ::97])
+    out["nsl"] = nsl.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g3_multimodal_pretraining.npz"), **out)
+    print("g3 ok", [float(x) for x in l])
+
+
+def g4(R):
+    """BASELINE config 4 shapes: fine-tune (pretrain=False), K=6, 7 frames x 36 = 252 regions, ranking (+traj) heads,
+    one ranking target = -1, plus the eval-mode BCE branch of get_loss_correct (utils_init.py:143-146)."""
+    rcfg, ocfg = load_cfg(R, "bert_base_6_layer_6_connect.json", **ZERO_DROP)
+    args = ref_args(ranking=True, traj_judge=True, pretrain=False, num_negatives=2)
+    model, W, _ = build_lily(R, rcfg, args, seed=15)
+    nb = synth.make_batch(bs=2, K=6, T=80, frames=7, boxes=36, seed=25, finetune_heading=True, ignore_rank_frac=0.0)
+    nb[0][1] = -1
+    out = {}
+    batch = synth.to_torch(nb)
+    _summaries(R, model, batch, args, ocfg, W, out)
+    # eval branch: multi-hot float target [bs,K] (weights reloaded: _summaries took an optimizer step)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    model.eval()
+    tgt = torch.zeros(2, 6, dtype=torch.bool); tgt[0, 0] = True; tgt[1, 2] = True; tgt[1, 3] = True
+    eb = list(batch); eb[0] = tgt
+    with torch.no_grad():
+        outputs = model(*R.utils_init.get_model_input(eb))
+        _, _, l, c = R.utils_init.get_loss_correct(eb, outputs, "ranking", args, None, False)
+        S = state_of(W)
+        ids, feat, loc, seg, imask, vmask = O.model_input(eb)
+        oo = O.lily_forward(S, ocfg, flags_of(args), ids, feat, loc, seg, imask, vmask)
+        ol, oc = O.task_loss(eb, oo, "ranking", flags_of(args), training=False)
+    check("eval bce", l, ol, 1e-6, 1e-6); check("eval correct", c, oc)
+    out["eval/target"], out["eval/loss"], out["eval/correct"] = tgt.numpy(), np_(l), np_(c)
+    np.savez_compressed(os.path.join(GOLD, "g4_finetune_rank.npz"), **out)
+    print("g4 ok", {k: float(v) for k, v in out.items() if k.startswith("loss/")})
+
+
+def g5(R):
+    """Known-answer tests for single ops, produced by the reference's own functions / the torch ops it calls."""
+    rs = np.random.RandomState(5)
+    out = {}
+    x = torch.from_numpy(rs.standard_normal((7, 48)).astype(np.float32)); x[3] = 2.5   # a constant row
+    ln = R.vilbert.BertLayerNorm(48)
+    ln.weight.data = torch.from_numpy((1 + 0.1 * rs.standard_normal(48)).astype(np.float32))
+    ln.bias.data = torch.from_numpy((0.1 * rs.standard_normal(48)).astype(np.float32))
+    out["ln/x"], out["ln/w"], out["ln/b"], out["ln/y"] = x.numpy(), np_(ln.weight), np_(ln.bias), np_(ln(x))
+    check("ln", ln(x), O.layer_norm(x, ln.weight, ln.bias))
+    g = torch.from_numpy(np.linspace(-6, 6, 97).astype(np.float32))
+    out["gelu/x"], out["gelu/y"] = g.numpy(), R.vilbert.gelu(g).numpy()
+    check("gelu", R.vilbert.gelu(g), O._act("gelu", g), 1e-7, 1e-7)
+    # masked softmax with a fully masked tail and a fully masked row
+    s = torch.from_numpy(rs.standard_normal((2, 3, 5, 9)).astype(np.float32))
+    m = torch.ones(2, 9); m[0, 6:] = 0; m[1, :] = 0
+    add = (1.0 - m[:, None, None, :]) * -10000.0
+    out["softmax/s"], out["softmax/mask"], out["softmax/p"] = s.numpy(), m.numpy(), torch.softmax(s / 8 ** 0.5 + add, -1).numpy()
+    # pad_packed with ragged opt_mask
+    from utils.dataset.common import pad_packed
+    om = torch.tensor([[1, 1, 0], [1, 0, 1]], dtype=torch.bool)
+    t = torch.tensor([1.0, 2.0, 3.0, 4.0])
+    out["pad_packed/mask"], out["pad_packed/t"], out["pad_packed/out"] = om.numpy(), t.numpy(), pad_packed(t, om).numpy()
+    assert torch.equal(pad_packed(t, om), O.pad_packed(t, om))
+    # CE with ignore_index incl. all-ignored (NaN in the reference) and -inf padded ranking logits
+    import torch.nn.functional as F
+    lg = torch.from_numpy(rs.standard_normal((6, 13)).astype(np.float32))
+    tg = torch.tensor([3, -1, 0, 12, -1, 7])
+    out["ce/logits"], out["ce/target"], out["ce/loss"] = lg.numpy(), tg.numpy(), F.cross_entropy(lg, tg, ignore_index=-1).numpy()
+    out["ce/all_ignored"] = F.cross_entropy(lg, torch.full((6,), -1), ignore_index=-1).numpy()
+    lgi = lg.clone(); lgi[:, 10:] = -float("inf"); tgi = torch.tensor([3, -1, 0, 2, -1, 7])
+    out["ce/logits_inf"], out["ce/target_inf"], out["ce/loss_inf"] = lgi.numpy(), tgi.numpy(), F.cross_entropy(lgi, tgi, ignore_index=-1).numpy()
+    # KL masked: zero mask -> denominator clamps to 1 (utils_init.py:127); target with exact zeros
+    pr = torch.from_numpy(rs.standard_normal((5, 11)).astype(np.float32))
+    tt = torch.softmax(torch.from_numpy(rs.standard_normal((5, 11)).astype(np.float32)) * 3, -1); tt[2, :4] = 0
+    for nm, mk in (("some", torch.tensor([1, 0, 1, 1, 0])), ("none", torch.zeros(5, dtype=torch.long))):
+        kl = F.kl_div(F.log_softmax(pr, -1), tt, reduction="none") * mk.unsqueeze(-1).float()
+        out[f"kl/{nm}_mask"], out[f"kl/{nm}_loss"] = mk.numpy(), (kl.sum() / max(1, mk.sum().item())).numpy()
+    out["kl/pred"], out["kl/target"] = pr.numpy(), tt.numpy()
+    # BCE with pos_weight (utils_init.py:160-161) incl. -inf padded logits on negative targets
+    bl = torch.from_numpy(rs.standard_normal((3, 7)).astype(np.float32))
+    bt = torch.zeros(3, 7); bt[:, :3] = 1
+    pw = torch.tensor([7 / 3 - 1])
+    out["bce/logits"], out["bce/target"], out["bce/pos_weight"] = bl.numpy(), bt.numpy(), pw.numpy()
+    out["bce/loss"] = F.binary_cross_entropy_with_logits(bl, bt, pos_weight=pw).numpy()
+    # AdamW single tensor, 3 steps, with decay, via the reference optimizer
+    p0 = rs.standard_normal((4, 6)).astype(np.float32)
+    gs = rs.standard_normal((3, 4, 6)).astype(np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = R.optimization.AdamW([{"params": [p], "weight_decay": 0.01}], lr=1e-2)
+    st = O.AdamWState(); ps = {"w": torch.from_numpy(p0.copy())}
+    for i in range(3):
+        p.grad = torch.from_numpy(gs[i].copy()); opt.step()
+        O.adamw_step(ps, {"w": torch.from_numpy(gs[i])}, st, 1e-2, 0.01)
+        out[f"adamw/p{i + 1}"] = np_(p)
+    check("adamw", p, ps["w"], 1e-7, 1e-6)
+    out["adamw/p0"], out["adamw/grads"] = p0, gs
+    out["adamw/m"], out["adamw/v"] = np_(opt.state[p]["exp_avg"]), np_(opt.state[p]["exp_avg_sq"])
+    # LR schedule samples (WarmupLinearSchedule with vilbert_init.py totals)
+    warm, tot = O.schedule_totals(50, 1, 2)
+    sch = R.optimization.WarmupLinearSchedule(torch.optim.SGD([p], lr=1.0), warm, tot)
+    out["sched/steps"] = np.arange(0, 200, 7)
+    out["sched/lambda"] = np.array([sch.lr_lambda(int(s)) for s in out["sched/steps"]])
+    assert all(abs(O.warmup_linear(int(s), warm, tot) - l) < 1e-15 for s, l in zip(out["sched/steps"], out["sched/lambda"]))
+    out["sched/warm_total"] = np.array([warm, tot])
+    np.savez_compressed(os.path.join(GOLD, "g5_kats.npz"), **out)
+    print("g5 ok")
+
+
+def schema(R):
+    """State-dict key -> shape for every config and both top-level model classes, plus weight-decay group membership
+    as computed by the reference's own get_optimization (vilbert_init.py:9-18)."""
+    res = {}
+    for cfgname in ("micro.json", "tiny_2_2_1.json", "bert_base_6_layer_6_connect.json"):
+        rcfg, _ = load_cfg(R, cfgname)
+        rcfg.args = ref_args(ranking=True)
+        m = R.lily.Lily(rcfg)
+        opt, _, _, _ = R.vilbert_init.get_optimization(ref_args(no_scheduler=True), m, 10, None)
+        nodecay_ids = {id(p) for p in opt.param_groups[0]["params"]}
+        res["Lily/" + cfgname] = {
+            "shapes": {k: list(v.shape) for k, v in m.state_dict().items()},
+            "param_order": [n for n, _ in m.named_parameters()],
+            "no_decay": [n for n, p in m.named_parameters() if id(p) in nodecay_ids],
+            "n_params": int(sum(p.numel() for p in m.parameters())),
+        }
+        if cfgname != "bert_base_6_layer_6_connect.json":
+            mm = R.vilbert.BertForMultiModalPreTraining(rcfg)
+            res["BertForMultiModalPreTraining/" + cfgname] = {"shapes": {k: list(v.shape) for k, v in mm.state_dict().items()},
+                                                              "param_order": [n for n, _ in mm.named_parameters()]}
+    json.dump(res, open(os.path.join(GOLD, "state_dict_schema.json"), "w"), indent=0, sort_keys=True)
+    print("schema ok", {k: v.get("n_params") for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    R = ref_import.import_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    todo = sys.argv[1:] or ["g5", "g0", "g1", "g3", "schema", "g2", "g4"]
+    for name in todo:
+        globals()[name](R)

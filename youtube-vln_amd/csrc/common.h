@@ -1,0 +1,98 @@
+// Shared host/device helpers for libytvln (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+
+#include "../../include/ytvln.h"
+
+namespace ytvln {
+
+// ---- error reporting across the C ABI -------------------------------------------------------------------------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define YT_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return ::ytvln::fail(-1, __VA_ARGS__);    \
+    } while (0)
+
+#define YT_LAUNCH_CHECK(name)                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) return ::ytvln::fail(-2, "%s: %s", name, hipGetErrorString(e_));  \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- Philox4x32-10 counter RNG (dropout masks reproducible between forward and backward) ----------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// Key of one dropout site: rng[0] = seed, rng[1] = forward counter (device memory), site = host call-site id.
+struct DropKey { uint32_t k0, k1, s0, s1; };
+__device__ __forceinline__ DropKey make_drop_key(const int64_t* rng, int64_t site) {
+    const uint64_t seed = (uint64_t)rng[0], ctr = (uint64_t)rng[1];
+    const uint64_t mix = seed ^ (ctr * 0x9E3779B97F4A7C15ull);
+    return {(uint32_t)mix, (uint32_t)(mix >> 32), (uint32_t)site, (uint32_t)((uint64_t)site >> 32) ^ (uint32_t)(ctr >> 17)};
+}
+// Four keep-flags/uniforms for elements [4*q, 4*q+3] of the site's flat element space.
+__device__ __forceinline__ u32x4 drop_bits(const DropKey& k, uint64_t q) {
+    return philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), k.s0, k.s1, k.k0, k.k1);
+}
+__device__ __forceinline__ uint32_t drop_threshold(float p) {
+    // keep iff bits >= thr ; P(drop) = thr / 2^32
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+// keep-scale for a single element e of the site (recomputes the 4-group; use the vector form on hot paths)
+__device__ __forceinline__ float drop_scale1(const DropKey& k, uint64_t e, uint32_t thr, float inv_keep) {
+    const u32x4 b = drop_bits(k, e >> 2);
+    const uint32_t sel = (e & 3) == 0 ? b.x : (e & 3) == 1 ? b.y : (e & 3) == 2 ? b.z : b.w;
+    return sel >= thr ? inv_keep : 0.0f;
+}
+
+// ---- wave / block reductions ------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact erf-GELU (vilbert/vilbert.py:119) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective remap of a linear workgroup id (8 XCDs, round-robin dispatch): consecutive remapped ids share an
+// XCD (and therefore an L2).  cdna guide T1 (bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace ytvln

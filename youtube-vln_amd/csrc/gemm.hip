@@ -1,0 +1,223 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, register-prefetched, double-buffered.
+//
+// Replaces every nn.Linear on the ViLBERT path and its backward (see include/ytvln.h).  fp32-in / fp32-accumulate MFMA
+// is bit-for-bit an fmaf chain (MI355X guide section 3), so parity with the reference's fp32 arithmetic holds to rounding order.
+//
+// Tiling: workgroup = 256 threads = 4 waves (2x2); block tile BM x BN x 32; each wave owns (BM/2) x (BN/2) as a grid of
+// 32x32 MFMA tiles.  LDS holds both operands k-major ( S[k][m] ) so a wave's operand fetch is 32 consecutive floats per
+// half-wave (conflict-free ds_read_b32): lane l supplies A[m = l&31][k = l>>5] and B[k = l>>5][n = l&31].
+// Operands whose K dimension is contiguous in memory (x[M,K], nn.Linear weight [N,K]) are transposed on the LDS write
+// (row pitch BM+1 -> conflict-free); operands with M/N contiguous (dY^T, x^T views for the backward GEMMs) are written
+// with 16-byte stores (row pitch BM).
+#include "common.h"
+
+namespace ytvln {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; float* aux;
+    int64_t lda, ldb, ldc, ldaux;
+    int M, N, K;
+    int epilogue;
+    float beta;
+    int vecA, vecB;   // 16-byte aligned vector loads legal for the operand
+    int tiles_n, ntiles;
+};
+
+constexpr int BK = 32;
+
+template <int BMN, bool KC>
+struct TileLoader {
+    // number of float4 per thread for a BMN x 32 tile with 256 threads
+    static constexpr int NV = BMN * BK / 4 / 256;
+    static constexpr int LD = KC ? BMN + 1 : BMN;
+
+    // global -> registers. mn0: first row/col of the tile in the M/N dimension, k0: first k.
+    __device__ static __forceinline__ void load(float4 (&r)[NV], const float* __restrict__ P, int64_t ld, int MN, int K,
+                                                int mn0, int k0, int vec, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = tid + 256 * j;
+            int mn, k;
+            if (KC) { mn = idx >> 3; k = (idx & 7) << 2; }                       // 8 float4 along k per row
+            else { k = idx / (BMN / 4); mn = (idx % (BMN / 4)) << 2; }           // BMN/4 float4 along mn per k-row
+            const int gmn = mn0 + mn, gk = k0 + k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                if (gmn < MN && gk < K) {
+                    const float* p = P + (int64_t)gmn * ld + gk;
+                    if (vec && gk + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        v.x = p[0];
+                        if (gk + 1 < K) v.y = p[1];
+                        if (gk + 2 < K) v.z = p[2];
+                        if (gk + 3 < K) v.w = p[3];
+                    }
+                }
+            } else {
+                if (gk < K && gmn < MN) {
+                    const float* p = P + (int64_t)gk * ld + gmn;
+                    if (vec && gmn + 3 < MN) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        v.x = p[0];
+                        if (gmn + 1 < MN) v.y = p[1];
+                        if (gmn + 2 < MN) v.z = p[2];
+                        if (gmn + 3 < MN) v.w = p[3];
+                    }
+                }
+            }
+            r[j] = v;
+        }
+    }
+    // registers -> LDS (k-major image S[k][mn])
+    __device__ static __forceinline__ void store(const float4 (&r)[NV], float* __restrict__ S, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = tid + 256 * j;
+            if (KC) {
+                const int mn = idx >> 3, k = (idx & 7) << 2;
+                S[(k + 0) * LD + mn] = r[j].x;
+                S[(k + 1) * LD + mn] = r[j].y;
+                S[(k + 2) * LD + mn] = r[j].z;
+                S[(k + 3) * LD + mn] = r[j].w;
+            } else {
+                const int k = idx / (BMN / 4), mn = (idx % (BMN / 4)) << 2;
+                *reinterpret_cast<float4*>(S + k * LD + mn) = r[j];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    using LA = TileLoader<BM, A_KC>;
+    using LB = TileLoader<BN, B_KC>;
+    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave along m / n (2x2 waves)
+    constexpr int SA = BK * LA::LD, SB = BK * LB::LD;  // floats per buffer
+    __shared__ __attribute__((aligned(16))) float smem[2 * SA + 2 * SB];
+    float* As = smem;
+    float* Bs = smem + 2 * SA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+    const int t = xcd_remap(blockIdx.x, g.ntiles);
+    const int m0 = (t / g.tiles_n) * BM, n0 = (t % g.tiles_n) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[LA::NV], rb[LB::NV];
+    const int nk = (g.K + BK - 1) / BK;
+    LA::load(ra, g.A, g.lda, g.M, g.K, m0, 0, g.vecA, tid);
+    LB::load(rb, g.B, g.ldb, g.N, g.K, n0, 0, g.vecB, tid);
+    LA::store(ra, As, tid);
+    LB::store(rb, Bs, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            LA::load(ra, g.A, g.lda, g.M, g.K, m0, (kt + 1) * BK, g.vecA, tid);
+            LB::load(rb, g.B, g.ldb, g.N, g.K, n0, (kt + 1) * BK, g.vecB, tid);
+        }
+        const float* a_s = As + cur * SA + half * LA::LD + wm0 + l31;
+        const float* b_s = Bs + cur * SB + half * LB::LD + wn0 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_s[kk * LA::LD + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_s[kk * LB::LD + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            LA::store(ra, As + (cur ^ 1) * SA, tid);
+            LB::store(rb, Bs + (cur ^ 1) * SB, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane owns column l31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + 32 * j + l31;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                float* cp = g.C + (int64_t)row * g.ldc + col;
+                switch (g.epilogue) {
+                    case YTVLN_EPI_GELU:
+                        if (g.aux) g.aux[(int64_t)row * g.ldaux + col] = v;
+                        v = gelu_erf(v);
+                        break;
+                    case YTVLN_EPI_RELU: v = fmaxf(v, 0.f); break;
+                    case YTVLN_EPI_MUL_DGELU: v *= dgelu_erf(g.aux[(int64_t)row * g.ldaux + col]); break;
+                    case YTVLN_EPI_MUL_DRELU: v = g.aux[(int64_t)row * g.ldaux + col] > 0.f ? v : 0.f; break;
+                    default: break;
+                }
+                if (g.beta != 0.f) v += g.beta * *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
+    g.tiles_n = (int)cdiv(g.N, BN);
+    g.ntiles = (int)cdiv(g.M, BM) * g.tiles_n;
+    dim3 grid(g.ntiles), block(256);
+    if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
+    return 0;
+}
+
+}  // namespace ytvln
+
+using namespace ytvln;
+
+extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                              int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
+                              int epilogue, float beta, void* stream) {
+    YT_REQUIRE(A && B && C, "gemm: null operand");
+    YT_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
+    YT_REQUIRE(epilogue >= YTVLN_EPI_NONE && epilogue <= YTVLN_EPI_MUL_DRELU, "gemm: bad epilogue %d", epilogue);
+    YT_REQUIRE(!(epilogue >= YTVLN_EPI_MUL_DGELU) || aux, "gemm: epilogue %d needs aux", epilogue);
+    YT_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "gemm: leading dimension too small");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+    g.M = M; g.N = N; g.K = K; g.epilogue = epilogue; g.beta = beta;
+    g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+    g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+    hipStream_t s = as_stream(stream);
+    // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (256 CUs, 2 resident 128x128 blocks/CU)
+    const int64_t b128 = cdiv(M, 128) * cdiv(N, 128), b12864 = cdiv(M, 128) * cdiv(N, 64);
+    if (b128 >= 384) launch_tile<128, 128>(g, transA, transB, s);
+    else if (b12864 >= 384) launch_tile<128, 64>(g, transA, transB, s);
+    else launch_tile<64, 64>(g, transA, transB, s);
+    YT_LAUNCH_CHECK("gemm_f32");
+    return 0;
+}
