@@ -93,7 +93,7 @@ def ref_losses(R, batch, outputs, args, training=True):
 
 
 def np_(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()      # copy: CPU tensors share storage with .numpy() and are updated in place
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,479 @@
+// Fused multi-head attention (forward + backward) on the CDNA4 fp32 matrix cores.
+//
+// One code path serves BertSelfAttention, BertImageSelfAttention and both directions of BertBiAttention
+// (vilbert/vilbert.py:284-311, 413-440, 552-618): queries and keys/values may come from different streams (Tq != Tk) and
+// are read in place from the packed projection outputs through (pointer, leading dimension) pairs.
+//
+// Register-resident flash attention, designed around the 32x32x2 f32 MFMA fragment layout so that no score ever leaves
+// the register file and no cross-lane shuffle is needed beyond one half-wave exchange:
+//   * a wave owns 32 queries; it computes the TRANSPOSED score tile  S^T[key][query] = K . Q^T  so that the accumulator
+//     layout (column = lane&31 = query, 16 keys down the registers, the other 16 keys in the partner half-wave) makes the
+//     softmax reduction over keys a per-lane loop + one __shfl_xor(32);
+//   * the probabilities are consumed straight from those registers as the B operand of  O^T[dcol][query] += V^T . P^T,
+//     because "reg r of lane l" is exactly the (k = key, column = query) element the MFMA wants when the contraction
+//     index is visited in the permuted order key(r, half) = (r&3) + 8*(r>>2) + 4*half  (a sum is order-free);
+//   * the contraction over the head dimension is split between half-waves (half 0: dk in [0, DP/2), half 1: the rest) so
+//     each lane fetches its K operand with ds_read_b128 from a row padded by 4 floats (conflict-free, section LDS of the guide);
+//   * O^T keeps the query on the lane, so the online-softmax rescale and the final 1/l are per-lane scalars.
+// K/V tiles of 32 keys are staged in LDS once per workgroup (NW waves = 32*NW queries share them).
+//
+// Backward = recompute-based flash backward split in two kernels with the same fragment tricks:
+//   dq kernel  (workgroup owns queries, loops over key tiles):  S^T, dP^T = V . dO^T, dS^T -> dQ^T += K^T . dS^T
+//   dkv kernel (workgroup owns keys,    loops over query tiles): S, dP = dO . V^T, -> dV^T += dO^T . P~, dK^T += Q^T . dS
+// The head dimension d may be any multiple of 4 up to 128; it is zero-padded to DP in {32, 64, 128}.
+#include "common.h"
+#include <algorithm>
+
+namespace ytvln {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v; const float* mask;
+    const float* ctx; const float* dctx; const float* lse; const float* delta;
+    float* out; float* lse_out; float* dq; float* dk; float* dv;
+    int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int N, heads, Tq, Tk, d;
+    float scale, p_drop;
+    const int64_t* rng; int64_t site;
+};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int krow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// scaled + masked score with the reference's two roundings (scores / sqrt(d), then + mask; vilbert.py:295-297): the
+// additive mask is -10000, so an fma here would change fully-masked rows at the 1e-3 level.
+__device__ __forceinline__ float score(float s, float scale, float mask) { return __fadd_rn(__fmul_rn(s, scale), mask); }
+
+// cooperative global -> LDS copy of a 32-row tile of head `h` (rows row0.., zero-filled past nrows / past d)
+template <int DP, int LD>
+__device__ __forceinline__ void stage_tile(float* __restrict__ S, const float* __restrict__ base, int64_t ld, int64_t row_base,
+                                           int row0, int nrows, int col0, int d, int tid, int nthr) {
+    constexpr int C4 = DP / 4;
+    for (int idx = tid; idx < 32 * C4; idx += nthr) {
+        const int row = idx / C4, c4 = idx % C4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < nrows && c4 * 4 < d)
+            v = *reinterpret_cast<const float4*>(base + (row_base + row0 + row) * ld + col0 + c4 * 4);
+        *reinterpret_cast<float4*>(S + row * LD + c4 * 4) = v;
+    }
+}
+
+// per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1
+template <int DP>
+__device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __restrict__ base, int64_t ld, int64_t row_base,
+                                             int row, int nrows, int col0, int d, int half) {
+#pragma unroll
+    for (int s4 = 0; s4 < DP / 2; s4 += 4) {
+        const int col = half * (DP / 2) + s4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows && col < d) v = *reinterpret_cast<const float4*>(base + (row_base + row) * ld + col0 + col);
+        R[s4] = v.x; R[s4 + 1] = v.y; R[s4 + 2] = v.z; R[s4 + 3] = v.w;
+    }
+}
+
+// acc (32x32) = Xs-tile (rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T
+template <int DP, int LD>
+__device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], int l31, int half) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xr = Xs + l31 * LD + half * (DP / 2);
+#pragma unroll
+    for (int s4 = 0; s4 < DP / 2; s4 += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(xr + s4);
+        acc = MFMA(x.x, R[s4], acc);
+        acc = MFMA(x.y, R[s4 + 1], acc);
+        acc = MFMA(x.z, R[s4 + 2], acc);
+        acc = MFMA(x.w, R[s4 + 3], acc);
+    }
+    return acc;
+}
+
+// acc[c] (dcol x lane-col) += Xs^T (rows = dcol, contraction over the 32 tile rows in krow order) . P (own registers)
+template <int DP, int LD>
+__device__ __forceinline__ void mma_cols(f32x16 (&acc)[DP / 32], const float* __restrict__ Xs, const float (&P)[16], int l31,
+                                         int half, int d) {
+#pragma unroll
+    for (int c = 0; c < DP / 32; ++c) {
+        if (c * 32 < d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c] = MFMA(Xs[krow(r, half) * LD + c * 32 + l31], P[r], acc[c]);
+        }
+    }
+}
+
+// O^T-style accumulators -> global rows (row = this lane's query/key), scaled
+template <int DP>
+__device__ __forceinline__ void store_cols(const f32x16 (&acc)[DP / 32], float* __restrict__ base, int64_t ld, int64_t grow,
+                                           int col0, int d, int half, float mul) {
+#pragma unroll
+    for (int c = 0; c < DP / 32; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = c * 32 + 8 * g + 4 * half;
+            if (col < d)
+                *reinterpret_cast<float4*>(base + grow * ld + col0 + col) =
+                    make_float4(acc[c][4 * g] * mul, acc[c][4 * g + 1] * mul, acc[c][4 * g + 2] * mul, acc[c][4 * g + 3] * mul);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int DP, bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+    constexpr int LDK = DP + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;              // [32][LDK]
+    float* Vs = Ks + 32 * LDK;     // [32][DP]
+    float* Ms = Vs + 32 * DP;      // [32] additive mask of the tile (-inf past Tk)
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z, h = blockIdx.y;
+    const int qi = (blockIdx.x * (nthr >> 6) + wave) * 32 + l31;
+    const bool qvalid = qi < a.Tq;
+    const int col0 = h * a.d;
+
+    float Qr[DP / 2];
+    load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+
+    f32x16 O[DP / 32];
+#pragma unroll
+    for (int c = 0; c < DP / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr = 0; float ik = 1.f;
+    const int64_t tk4 = (a.Tk + 3) >> 2;
+    const int64_t drow = (((int64_t)n * a.heads + h) * a.Tq + qi) * tk4;
+    if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
+
+    for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+        __syncthreads();
+        stage_tile<DP, LDK>(Ks, a.k, a.ldk, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
+        stage_tile<DP, DP>(Vs, a.v, a.ldv, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
+        if (tid < 32) Ms[tid] = (j0 + tid < a.Tk) ? (a.mask ? a.mask[(int64_t)n * a.Tk + j0 + tid] : 0.f) : -INFINITY;
+        __syncthreads();
+
+        const f32x16 S = mma_rows<DP, LDK>(Ks, Qr, l31, half);
+        float P[16];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 mk = *reinterpret_cast<const float4*>(Ms + 8 * g + 4 * half);
+            P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
+            P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, P[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m, mt);
+        const float alpha = expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { P[r] = expf(P[r] - mn); ps += P[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int c = 0; c < DP / 32; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        if (DROP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 b = drop_bits(key, (uint64_t)(drow + ((j0 + 8 * g + 4 * half) >> 2)));
+                P[4 * g] = b.x >= thr ? P[4 * g] * ik : 0.f; P[4 * g + 1] = b.y >= thr ? P[4 * g + 1] * ik : 0.f;
+                P[4 * g + 2] = b.z >= thr ? P[4 * g + 2] * ik : 0.f; P[4 * g + 3] = b.w >= thr ? P[4 * g + 3] * ik : 0.f;
+            }
+        }
+        mma_cols<DP, DP>(O, Vs, P, l31, half, a.d);
+    }
+    if (qvalid) {
+        store_cols<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq + qi, col0, a.d, half, 1.0f / l);
+        if (half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
+    }
+}
+
+// delta[n,h,q] = sum_c dctx[n,q,h*d+c] * ctx[n,q,h*d+c]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ ctx, const float* __restrict__ dctx, int64_t ldo,
+                                                         float* __restrict__ delta, int N, int heads, int Tq, int d) {
+    const int64_t total = (int64_t)N * Tq * heads;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int h = (int)(i % heads);
+        const int64_t row = i / heads;   // n*Tq + q
+        const float4* o = reinterpret_cast<const float4*>(ctx + row * ldo + h * d);
+        const float4* g = reinterpret_cast<const float4*>(dctx + row * ldo + h * d);
+        float acc = 0.f;
+        for (int c = 0; c < d / 4; ++c) {
+            const float4 x = o[c], y = g[c];
+            acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+        const int64_t nn = row / Tq, q = row % Tq;
+        delta[(nn * heads + h) * Tq + q] = acc;
+    }
+}
+
+template <int DP, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+    constexpr int LDK = DP + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;              // [32][LDK]
+    float* Vs = Ks + 32 * LDK;     // [32][LDK]
+    float* Ms = Vs + 32 * LDK;     // [32]
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z, h = blockIdx.y;
+    const int qi = (blockIdx.x * (nthr >> 6) + wave) * 32 + l31;
+    const bool qvalid = qi < a.Tq;
+    const int col0 = h * a.d;
+
+    float Qr[DP / 2], Gr[DP / 2];
+    load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+    load_rowfrag<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+    const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
+    const float lse = qvalid ? a.lse[sidx] : 0.f;
+    const float dl = qvalid ? a.delta[sidx] : 0.f;
+
+    f32x16 dQ[DP / 32];
+#pragma unroll
+    for (int c = 0; c < DP / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQ[c][r] = 0.f;
+
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr = 0; float ik = 1.f;
+    const int64_t tk4 = (a.Tk + 3) >> 2;
+    const int64_t drow = sidx * tk4;
+    if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
+
+    for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+        __syncthreads();
+        stage_tile<DP, LDK>(Ks, a.k, a.ldk, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
+        stage_tile<DP, LDK>(Vs, a.v, a.ldv, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
+        if (tid < 32) Ms[tid] = (j0 + tid < a.Tk) ? (a.mask ? a.mask[(int64_t)n * a.Tk + j0 + tid] : 0.f) : -INFINITY;
+        __syncthreads();
+
+        const f32x16 S = mma_rows<DP, LDK>(Ks, Qr, l31, half);
+        const f32x16 dP = mma_rows<DP, LDK>(Vs, Gr, l31, half);
+        float dS[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 mk = *reinterpret_cast<const float4*>(Ms + 8 * g + 4 * half);
+            const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            u32x4 b = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (DROP) b = drop_bits(key, (uint64_t)(drow + ((j0 + 8 * g + 4 * half) >> 2)));
+            const uint32_t bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * g + u;
+                const float p = expf(score(S[r], a.scale, mkv[u]) - lse);
+                const float dp = DROP ? (bb[u] >= thr ? dP[r] * ik : 0.f) : dP[r];
+                dS[r] = p * (dp - dl);
+            }
+        }
+        mma_cols<DP, LDK>(dQ, Ks, dS, l31, half, a.d);
+    }
+    if (qvalid) store_cols<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq + qi, col0, a.d, half, a.scale);
+}
+
+template <int DP, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    constexpr int LDK = DP + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;               // [32][LDK]  query tile
+    float* Gs = Qs + 32 * LDK;      // [32][LDK]  dctx tile
+    float* Ls = Gs + 32 * LDK;      // [32] lse   (+inf past Tq -> p = 0)
+    float* Ds = Ls + 32;            // [32] delta
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z, h = blockIdx.y;
+    const int kj = (blockIdx.x * (nthr >> 6) + wave) * 32 + l31;    // this lane's key
+    const bool kvalid = kj < a.Tk;
+    const int col0 = h * a.d;
+
+    float Kr[DP / 2], Vr[DP / 2];
+    load_rowfrag<DP>(Kr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    load_rowfrag<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
+
+    f32x16 dK[DP / 32], dV[DP / 32];
+#pragma unroll
+    for (int c = 0; c < DP / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dK[c][r] = 0.f; dV[c][r] = 0.f; }
+
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr = 0; float ik = 1.f;
+    const int64_t tk4 = (a.Tk + 3) >> 2;
+    if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
+    const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
+
+    for (int i0 = 0; i0 < a.Tq; i0 += 32) {
+        __syncthreads();
+        stage_tile<DP, LDK>(Qs, a.q, a.ldq, (int64_t)n * a.Tq, i0, a.Tq, col0, a.d, tid, nthr);
+        stage_tile<DP, LDK>(Gs, a.dctx, a.ldo, (int64_t)n * a.Tq, i0, a.Tq, col0, a.d, tid, nthr);
+        if (tid < 32) {
+            const bool ok = i0 + tid < a.Tq;
+            Ls[tid] = ok ? a.lse[srow + i0 + tid] : INFINITY;
+            Ds[tid] = ok ? a.delta[srow + i0 + tid] : 0.f;
+        }
+        __syncthreads();
+
+        // S[query][key] and dP[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
+        const f32x16 S = mma_rows<DP, LDK>(Qs, Kr, l31, half);
+        const f32x16 dP = mma_rows<DP, LDK>(Gs, Vr, l31, half);
+        float Pt[16], dS[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 ls = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * half);
+            const float4 ds = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * half);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * g + u;
+                const float p = expf(score(S[r], a.scale, mk) - lsv[u]);
+                float keep = 1.f;
+                if (DROP) {
+                    const int qq = i0 + 8 * g + 4 * half + u;
+                    const uint64_t e = (uint64_t)((srow + qq) * tk4) * 4ull + (uint64_t)kj;
+                    keep = drop_scale1(key, e, thr, ik);
+                }
+                Pt[r] = p * keep;
+                dS[r] = p * (dP[r] * keep - dsv[u]);
+            }
+        }
+        mma_cols<DP, LDK>(dV, Gs, Pt, l31, half, a.d);
+        mma_cols<DP, LDK>(dK, Qs, dS, l31, half, a.d);
+    }
+    if (kvalid) {
+        store_cols<DP>(dV, a.dv, a.lddv, (int64_t)n * a.Tk + kj, col0, a.d, half, 1.0f);
+        store_cols<DP>(dK, a.dk, a.lddk, (int64_t)n * a.Tk + kj, col0, a.d, half, a.scale);
+    }
+}
+
+// diagnostic: materialise attention_probs (reference returns them when output_all_attention_masks=True)
+__global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                         int64_t ldk, const float* __restrict__ mask, const float* __restrict__ lse,
+                                                         float* __restrict__ probs, int N, int heads, int Tq, int Tk, int d,
+                                                         float scale) {
+    const int64_t total = (int64_t)N * heads * Tq * Tk;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i % Tk);
+        int64_t t = i / Tk;
+        const int qi = (int)(t % Tq); t /= Tq;
+        const int h = (int)(t % heads);
+        const int64_t n = t / heads;
+        const float* qp = q + (n * Tq + qi) * ldq + h * d;
+        const float* kp = k + (n * Tk + j) * ldk + h * d;
+        float acc = 0.f;
+        for (int c = 0; c < d; ++c) acc = fmaf(qp[c], kp[c], acc);
+        probs[i] = expf(score(acc, scale, mask ? mask[n * Tk + j] : 0.f) - lse[(n * heads + h) * Tq + qi]);
+    }
+}
+
+static int pick_waves(int T) {
+    // waves per workgroup (32 rows each): least padding first, then the most waves (they share the staged tiles)
+    int best = 1, best_pad = 1 << 30;
+    for (int nw = 4; nw >= 1; --nw) {
+        const int pad = (int)cdiv(T, 32 * nw) * 32 * nw - T;
+        if (pad < best_pad) { best_pad = pad; best = nw; }
+    }
+    return best;
+}
+
+static int check_common(const char* who, const AttnArgs& a) {
+    YT_REQUIRE(a.q && a.k && a.v, "%s: null q/k/v", who);
+    YT_REQUIRE(a.N > 0 && a.heads > 0 && a.Tq > 0 && a.Tk > 0, "%s: empty problem", who);
+    YT_REQUIRE(a.d > 0 && a.d % 4 == 0 && a.d <= 128, "%s: head dim %d unsupported (multiple of 4, <= 128)", who, a.d);
+    YT_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "%s: leading dimensions must be multiples of 4", who);
+    YT_REQUIRE(((uintptr_t)a.q & 15) == 0 && ((uintptr_t)a.k & 15) == 0 && ((uintptr_t)a.v & 15) == 0, "%s: q/k/v must be 16-byte aligned", who);
+    YT_REQUIRE(a.p_drop >= 0.f && a.p_drop < 1.f, "%s: p_drop out of range", who);
+    YT_REQUIRE(!(a.p_drop > 0.f) || a.rng, "%s: dropout needs rng state", who);
+    YT_REQUIRE(a.N <= 65535 && a.heads <= 65535, "%s: grid too large", who);
+    return 0;
+}
+
+#define DISPATCH_DP_DROP(KERNEL, grid, block, lds_fn, s, a)                                                   \
+    do {                                                                                                     \
+        const bool drop_ = (a).p_drop > 0.f;                                                                 \
+        if ((a).d <= 32) {                                                                                   \
+            if (drop_) hipLaunchKernelGGL((KERNEL<32, true>), grid, block, lds_fn(32), s, a);                \
+            else hipLaunchKernelGGL((KERNEL<32, false>), grid, block, lds_fn(32), s, a);                     \
+        } else if ((a).d <= 64) {                                                                            \
+            if (drop_) hipLaunchKernelGGL((KERNEL<64, true>), grid, block, lds_fn(64), s, a);                \
+            else hipLaunchKernelGGL((KERNEL<64, false>), grid, block, lds_fn(64), s, a);                     \
+        } else {                                                                                             \
+            if (drop_) hipLaunchKernelGGL((KERNEL<128, true>), grid, block, lds_fn(128), s, a);              \
+            else hipLaunchKernelGGL((KERNEL<128, false>), grid, block, lds_fn(128), s, a);                   \
+        }                                                                                                    \
+    } while (0)
+
+static size_t lds_fwd(int dp) { return (size_t)(32 * (dp + 4) + 32 * dp + 32) * sizeof(float); }
+static size_t lds_bwd(int dp) { return (size_t)(2 * 32 * (dp + 4) + 64) * sizeof(float); }
+
+}  // namespace ytvln
+
+using namespace ytvln;
+
+extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                                  int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.mask = mask; a.out = ctx; a.lse_out = lse;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
+    if (int rc = check_common("attn_fwd", a)) return rc;
+    YT_REQUIRE(ctx && lse && ((uintptr_t)ctx & 15) == 0, "attn_fwd: ctx/lse null or misaligned");
+    const int nw = pick_waves(Tq);
+    dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
+    hipStream_t s = as_stream(stream);
+    DISPATCH_DP_DROP(attn_fwd_kernel, grid, block, lds_fwd, s, a);
+    YT_LAUNCH_CHECK("attn_fwd");
+    return 0;
+}
+
+extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
+                                  float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                                  int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
+                                  int64_t site, void* stream) {
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta;
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
+    if (int rc = check_common("attn_bwd", a)) return rc;
+    YT_REQUIRE(ctx && dctx && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
+    YT_REQUIRE(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: gradient leading dimensions must be multiples of 4");
+    YT_REQUIRE((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0, "attn_bwd: misaligned pointer");
+    hipStream_t s = as_stream(stream);
+    const int64_t total = (int64_t)N * Tq * heads;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, s, ctx, dctx, ldo,
+                       delta, N, heads, Tq, d);
+    {
+        const int nw = pick_waves(Tq);
+        dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
+        DISPATCH_DP_DROP(attn_bwd_dq_kernel, grid, block, lds_bwd, s, a);
+    }
+    {
+        const int nw = pick_waves(Tk);
+        dim3 grid((unsigned)cdiv(Tk, 32 * nw), heads, N), block(64 * nw);
+        DISPATCH_DP_DROP(attn_bwd_dkv_kernel, grid, block, lds_bwd, s, a);
+    }
+    YT_LAUNCH_CHECK("attn_bwd");
+    return 0;
+}
+
+extern "C" int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,
+                                    float* probs, int N, int heads, int Tq, int Tk, int d, float scale, void* stream) {
+    YT_REQUIRE(q && k && lse && probs, "attn_probs: null pointer");
+    const int64_t total = (int64_t)N * heads * Tq * Tk;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, as_stream(stream), q, ldq,
+                       k, ldk, mask, lse, probs, N, heads, Tq, Tk, d, scale);
+    YT_LAUNCH_CHECK("attn_probs");
+    return 0;
+}

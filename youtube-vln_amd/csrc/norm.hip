@@ -1,0 +1,448 @@
+// HBM-bound kernels of the ViLBERT path: fused (dropout/)residual/LayerNorm forward+backward, the two embedding front
+// ends, activation backward, dropout, column reductions and embedding-gradient scatters.
+//
+// Layout rule for all of them: one 64-lane wave owns one row of H floats, every lane moves 16-byte vectors
+// (global_load_dwordx4), the row stays in registers between the two reduction passes (mean, then centred variance as the
+// reference computes it, vilbert.py:214-216), so each element is read once and written once.
+#include "common.h"
+
+namespace ytvln {
+
+enum { LN_PLAIN = 0, LN_TEXT = 1, LN_IMAGE = 2 };
+
+struct LnArgs {
+    // plain
+    const float* x; const float* res;
+    // text embedding
+    const int64_t* ids; const int64_t* type_ids; const float* word; const float* pos; const float* type; int T;
+    // image embedding
+    const float* loc; const float* W5; const float* b5; const float* W4; const float* b4; const float* W2;
+    const float* b2; const float* E;
+    // common
+    const float* gamma; const float* beta; float* y; float* s_out; float* mean; float* rstd;
+    int64_t rows; int H; float eps; float p_pre, p_post; const int64_t* rng; int64_t site;
+};
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4scale_keep(float4 v, u32x4 b, uint32_t thr, float ik) {
+    return make_float4(b.x >= thr ? v.x * ik : 0.f, b.y >= thr ? v.y * ik : 0.f, b.z >= thr ? v.z * ik : 0.f,
+                       b.w >= thr ? v.w * ik : 0.f);
+}
+
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H4 = a.H >> 2;
+    const float invH = 1.0f / (float)a.H;
+    const bool pre = a.p_pre > 0.f, post = a.p_post > 0.f;
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr_pre = 0, thr_post = 0;
+    float ik_pre = 1.f, ik_post = 1.f;
+    if (pre || post) {
+        key = make_drop_key(a.rng, a.site);
+        thr_pre = drop_threshold(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
+        thr_post = drop_threshold(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+        float4 s[NV];
+        float loc[12];
+        const float* wrow = nullptr; const float* prow = nullptr; const float* trow = nullptr; const float* erow = nullptr;
+        if (MODE == LN_TEXT) {
+            wrow = a.word + a.ids[row] * (int64_t)a.H;
+            prow = a.pos + (row % a.T) * (int64_t)a.H;
+            trow = a.type + (a.type_ids ? a.type_ids[row] : 0) * (int64_t)a.H;
+        }
+        if (MODE == LN_IMAGE) {
+            const float4* lp = reinterpret_cast<const float4*>(a.loc + row * 12);
+            const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2];
+            loc[0] = l0.x; loc[1] = l0.y; loc[2] = l0.z; loc[3] = l0.w; loc[4] = l1.x; loc[5] = l1.y; loc[6] = l1.z;
+            loc[7] = l1.w; loc[8] = l2.x; loc[9] = l2.y; loc[10] = l2.z; loc[11] = l2.w;
+            erow = a.E + (int64_t)((long)loc[11]) * a.H;   // .long() truncation, vilbert.py:1364
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c4 = lane + 64 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 < H4) {
+                if (MODE == LN_PLAIN) {
+                    v = reinterpret_cast<const float4*>(a.x + row * a.H)[c4];
+                    if (pre) v = f4scale_keep(v, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre);
+                    if (a.res) v = f4add(v, reinterpret_cast<const float4*>(a.res + row * a.H)[c4]);
+                } else if (MODE == LN_TEXT) {
+                    v = f4add(f4add(reinterpret_cast<const float4*>(wrow)[c4], reinterpret_cast<const float4*>(prow)[c4]),
+                              reinterpret_cast<const float4*>(trow)[c4]);
+                } else {
+                    const int c = c4 << 2;
+                    float o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* w5 = a.W5 + (c + u) * 5;
+                        const float* w4 = a.W4 + (c + u) * 4;
+                        const float* w2 = a.W2 + (c + u) * 2;
+                        float av = a.b5[c + u], bv = a.b4[c + u], cv = a.b2[c + u];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) av = fmaf(w5[q], loc[q], av);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bv = fmaf(w4[q], loc[5 + q], bv);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) cv = fmaf(w2[q], loc[9 + q], cv);
+                        o[u] = ((av + bv) + cv) + erow[c + u];   // a + b + c + d, vilbert.py:1365
+                    }
+                    v = f4add(reinterpret_cast<const float4*>(a.x + row * a.H)[c4], make_float4(o[0], o[1], o[2], o[3]));
+                }
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+            s[j] = v;
+        }
+        const float mu = wave_sum(sum) * invH;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (lane + 64 * j < H4) {
+                const float dx = s[j].x - mu, dy = s[j].y - mu, dz = s[j].z - mu, dw = s[j].w - mu;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+        const float var = wave_sum(sq) * invH;
+        const float sd = sqrtf(var + a.eps);
+        if (lane == 0) {
+            if (a.mean) a.mean[row] = mu;
+            if (a.rstd) a.rstd[row] = 1.0f / sd;
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 < H4) {
+                if (a.s_out) reinterpret_cast<float4*>(a.s_out + row * a.H)[c4] = s[j];
+                const float4 g = reinterpret_cast<const float4*>(a.gamma)[c4], b = reinterpret_cast<const float4*>(a.beta)[c4];
+                float4 o = make_float4(g.x * ((s[j].x - mu) / sd) + b.x, g.y * ((s[j].y - mu) / sd) + b.y,
+                                       g.z * ((s[j].z - mu) / sd) + b.z, g.w * ((s[j].w - mu) / sd) + b.w);
+                if (post) o = f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_post, ik_post);
+                reinterpret_cast<float4*>(a.y + row * a.H)[c4] = o;
+            }
+        }
+    }
+}
+
+struct LnBwdArgs {
+    const float* dy; const float* s; const float* mean; const float* rstd; const float* gamma;
+    float* ds; float* dx; float* partial;
+    int64_t rows; int H; int rows_per_block; float p_pre, p_post; const int64_t* rng; int64_t site;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2][H]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H4 = a.H >> 2;
+    const float invH = 1.0f / (float)a.H;
+    const bool pre = a.p_pre > 0.f, post = a.p_post > 0.f;
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr_pre = 0, thr_post = 0;
+    float ik_pre = 1.f, ik_post = 1.f;
+    if (pre || post) {
+        key = make_drop_key(a.rng, a.site);
+        thr_pre = drop_threshold(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
+        thr_post = drop_threshold(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
+    }
+    float4 dg[NV], db[NV], gm[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        dg[j] = make_float4(0.f, 0.f, 0.f, 0.f); db[j] = dg[j];
+        gm[j] = (lane + 64 * j < H4) ? reinterpret_cast<const float4*>(a.gamma)[lane + 64 * j] : dg[j];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+    const int64_t r1 = min(r0 + a.rows_per_block, a.rows);
+    for (int64_t row = r0 + wave; row < r1; row += 4) {
+        const float mu = a.mean[row], rs = a.rstd[row];
+        float4 g[NV], xh[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c4 = lane + 64 * j;
+            g[j] = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = g[j];
+            if (c4 < H4) {
+                float4 d = reinterpret_cast<const float4*>(a.dy + row * a.H)[c4];
+                if (post) d = f4scale_keep(d, drop_bits(key, (uint64_t)row * H4 + c4), thr_post, ik_post);
+                const float4 sv = reinterpret_cast<const float4*>(a.s + row * a.H)[c4];
+                xh[j] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
+                dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
+                db[j] = f4add(db[j], d);
+                g[j] = make_float4(d.x * gm[j].x, d.y * gm[j].y, d.z * gm[j].z, d.w * gm[j].w);
+                c1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+                c2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+            }
+        }
+        c1 = wave_sum(c1) * invH;
+        c2 = wave_sum(c2) * invH;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 < H4) {
+                float4 o = make_float4(rs * (g[j].x - c1 - xh[j].x * c2), rs * (g[j].y - c1 - xh[j].y * c2),
+                                       rs * (g[j].z - c1 - xh[j].z * c2), rs * (g[j].w - c1 - xh[j].w * c2));
+                reinterpret_cast<float4*>(a.ds + row * a.H)[c4] = o;
+                if (pre && a.dx)
+                    reinterpret_cast<float4*>(a.dx + row * a.H)[c4] =
+                        f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre);
+            }
+        }
+    }
+    // cross-wave reduction of the dgamma / dbeta partials, one [2,H] record per block
+    float* mine = red + wave * 2 * a.H;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < H4) {
+            reinterpret_cast<float4*>(mine)[c4] = dg[j];
+            reinterpret_cast<float4*>(mine + a.H)[c4] = db[j];
+        }
+    }
+    __syncthreads();
+    float* out = a.partial + (int64_t)blockIdx.x * 2 * a.H;
+    for (int i = threadIdx.x; i < 2 * a.H; i += 256)
+        out[i] = (red[i] + red[2 * a.H + i]) + (red[4 * a.H + i] + red[6 * a.H + i]);
+}
+
+// ---- column reductions --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                     float* __restrict__ out, int64_t ldo, int rpb) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rpb, r1 = min(r0 + rpb, M);
+    float acc = 0.f;
+    if (c < N)
+        for (int r = r0 + rl; r < r1; r += 4) acc += x[(int64_t)r * ldx + c];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        const int l = threadIdx.x;
+        out[(int64_t)blockIdx.y * ldo + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_by_index_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ idx_f, int64_t idx_stride,
+                                                              const int64_t* __restrict__ idx_i, int M, int N, int KT,
+                                                              float* __restrict__ out, int rpb) {
+    extern __shared__ float acc[];   // [4][KT][64]
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    float* mine = acc + (rl * KT) * 64 + l;
+    for (int k = 0; k < KT; ++k) mine[k * 64] = 0.f;
+    const int r0 = blockIdx.y * rpb, r1 = min(r0 + rpb, M);
+    if (c < N)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const int k = idx_i ? (int)idx_i[r] : (int)idx_f[(int64_t)r * idx_stride];
+            if (k >= 0 && k < KT) mine[k * 64] += x[(int64_t)r * ldx + c];
+        }
+    __syncthreads();
+    if (c < N)
+        for (int k = rl; k < KT; k += 4) {
+            const float* p = acc + k * 64 + l;
+            out[((int64_t)blockIdx.y * KT + k) * N + c] = (p[0] + p[KT * 64]) + (p[2 * KT * 64] + p[3 * KT * 64]);
+        }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const int64_t* __restrict__ idx, int M, int H,
+                                                               float* __restrict__ tg, int64_t skip) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+        const int64_t k = idx[r];
+        if (k == skip) continue;
+        float* dst = tg + k * (int64_t)H;
+        const float* src = x + (int64_t)r * ldx;
+        for (int c = lane; c < H; c += 64) unsafeAtomicAdd(dst + c, src[c]);
+    }
+}
+
+// ---- elementwise --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
+                                                      float* __restrict__ dz, int64_t n, int act) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 d = reinterpret_cast<const float4*>(dy)[i], z = reinterpret_cast<const float4*>(aux)[i];
+        float4 o;
+        if (act == YTVLN_EPI_GELU) o = make_float4(d.x * dgelu_erf(z.x), d.y * dgelu_erf(z.y), d.z * dgelu_erf(z.z), d.w * dgelu_erf(z.w));
+        else o = make_float4(z.x > 0.f ? d.x : 0.f, z.y > 0.f ? d.y : 0.f, z.z > 0.f ? d.z : 0.f, z.w > 0.f ? d.w : 0.f);
+        reinterpret_cast<float4*>(dz)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        dz[i] = act == YTVLN_EPI_GELU ? dy[i] * dgelu_erf(aux[i]) : (aux[i] > 0.f ? dy[i] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
+                                                      const int64_t* rng, int64_t site) {
+    const DropKey key = make_drop_key(rng, site);
+    const uint32_t thr = drop_threshold(p);
+    const float ik = 1.0f / (1.0f - p);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<float4*>(y)[i] = f4scale_keep(reinterpret_cast<const float4*>(x)[i], drop_bits(key, (uint64_t)i), thr, ik);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        y[i] = x[i] * drop_scale1(key, (uint64_t)i, thr, ik);
+    }
+}
+
+template <int MODE>
+static int launch_ln(const LnArgs& a, hipStream_t s) {
+    const int nv = (int)cdiv(a.H / 4, 64);
+    const int grid = (int)std::min<int64_t>(cdiv(a.rows, 4), 4096);
+    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, MODE>), dim3(grid), dim3(256), 0, s, a);
+    else if (nv <= 2) hipLaunchKernelGGL((ln_fwd_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_fwd_kernel<8, MODE>), dim3(grid), dim3(256), 0, s, a);
+    return 0;
+}
+
+static inline bool ln_shape_ok(int H) { return H > 0 && H % 4 == 0 && H <= 2048; }
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace ytvln
+
+using namespace ytvln;
+
+extern "C" int ytvln_ln_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                float* s_out, float* mean, float* rstd, int64_t rows, int H, float eps, float p_pre,
+                                float p_post, const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(x && gamma && beta && y, "ln_fwd: null pointer");
+    YT_REQUIRE(ln_shape_ok(H), "ln_fwd: H=%d unsupported (need H %% 4 == 0, H <= 2048)", H);
+    YT_REQUIRE(al16(x) && al16(y) && al16(gamma) && al16(beta) && (!res || al16(res)) && (!s_out || al16(s_out)),
+               "ln_fwd: pointers must be 16-byte aligned");
+    YT_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "ln_fwd: dropout p out of range");
+    YT_REQUIRE(!(p_pre > 0.f || p_post > 0.f) || rng, "ln_fwd: dropout needs rng state");
+    if (rows == 0) return 0;
+    LnArgs a = {};
+    a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.H = H; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
+    launch_ln<LN_PLAIN>(a, as_stream(stream));
+    YT_LAUNCH_CHECK("ln_fwd");
+    return 0;
+}
+
+extern "C" int ytvln_text_embed_fwd_f32(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos,
+                                        const float* type, const float* gamma, const float* beta, float* y, float* s_out,
+                                        float* mean, float* rstd, int64_t rows, int T, int H, float eps, float p_post,
+                                        const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(ids && word && pos && type && gamma && beta && y, "text_embed_fwd: null pointer");
+    YT_REQUIRE(ln_shape_ok(H) && T > 0, "text_embed_fwd: bad shape H=%d T=%d", H, T);
+    YT_REQUIRE(al16(word) && al16(pos) && al16(type) && al16(y) && al16(gamma) && al16(beta) && (!s_out || al16(s_out)),
+               "text_embed_fwd: pointers must be 16-byte aligned");
+    YT_REQUIRE(!(p_post > 0.f) || rng, "text_embed_fwd: dropout needs rng state");
+    if (rows == 0) return 0;
+    LnArgs a = {};
+    a.ids = ids; a.type_ids = type_ids; a.word = word; a.pos = pos; a.type = type; a.T = T;
+    a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.H = H; a.eps = eps; a.p_pre = 0.f; a.p_post = p_post; a.rng = rng; a.site = site;
+    launch_ln<LN_TEXT>(a, as_stream(stream));
+    YT_LAUNCH_CHECK("text_embed_fwd");
+    return 0;
+}
+
+extern "C" int ytvln_image_embed_fwd_f32(const float* img, const float* loc, const float* W5, const float* b5,
+                                         const float* W4, const float* b4, const float* W2, const float* b2,
+                                         const float* E, const float* gamma, const float* beta, float* y, float* s_out,
+                                         float* mean, float* rstd, int64_t rows, int H, float eps, float p_post,
+                                         const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(img && loc && W5 && b5 && W4 && b4 && W2 && b2 && E && gamma && beta && y, "image_embed_fwd: null pointer");
+    YT_REQUIRE(ln_shape_ok(H), "image_embed_fwd: H=%d unsupported", H);
+    YT_REQUIRE(al16(img) && al16(loc) && al16(y) && al16(gamma) && al16(beta) && (!s_out || al16(s_out)),
+               "image_embed_fwd: pointers must be 16-byte aligned");
+    YT_REQUIRE(!(p_post > 0.f) || rng, "image_embed_fwd: dropout needs rng state");
+    if (rows == 0) return 0;
+    LnArgs a = {};
+    a.x = img; a.loc = loc; a.W5 = W5; a.b5 = b5; a.W4 = W4; a.b4 = b4; a.W2 = W2; a.b2 = b2; a.E = E;
+    a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.H = H; a.eps = eps; a.p_pre = 0.f; a.p_post = p_post; a.rng = rng; a.site = site;
+    launch_ln<LN_IMAGE>(a, as_stream(stream));
+    YT_LAUNCH_CHECK("image_embed_fwd");
+    return 0;
+}
+
+extern "C" int ytvln_ln_bwd_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(rows, 16))); }
+
+extern "C" int ytvln_ln_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
+                                float* ds, float* dx, float* partial, int64_t rows, int H, float p_pre, float p_post,
+                                const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(dy && s && mean && rstd && gamma && ds && partial, "ln_bwd: null pointer");
+    YT_REQUIRE(ln_shape_ok(H), "ln_bwd: H=%d unsupported", H);
+    YT_REQUIRE(al16(dy) && al16(s) && al16(ds) && al16(gamma) && (!dx || al16(dx)), "ln_bwd: pointers must be 16-byte aligned");
+    YT_REQUIRE(!(p_pre > 0.f || p_post > 0.f) || rng, "ln_bwd: dropout needs rng state");
+    YT_REQUIRE(!(p_pre > 0.f) || dx, "ln_bwd: p_pre > 0 needs dx");
+    if (rows == 0) return 0;
+    LnBwdArgs a;
+    a.dy = dy; a.s = s; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.ds = ds; a.dx = dx; a.partial = partial;
+    a.rows = rows; a.H = H; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
+    const int nb = ytvln_ln_bwd_blocks(rows);
+    a.rows_per_block = (int)cdiv(rows, nb);
+    const int nv = (int)cdiv(H / 4, 64);
+    const size_t lds = (size_t)8 * H * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    if (nv <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(nb), dim3(256), lds, st, a);
+    else if (nv <= 2) hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3(nb), dim3(256), lds, st, a);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(nb), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(nb), dim3(256), lds, st, a);
+    YT_LAUNCH_CHECK("ln_bwd");
+    return 0;
+}
+
+extern "C" int ytvln_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, int64_t ldo, int rows_per_block,
+                                void* stream) {
+    YT_REQUIRE(x && out && M >= 0 && N > 0 && rows_per_block > 0, "colsum: bad argument");
+    const int nb = (int)std::max<int64_t>(1, cdiv(M, rows_per_block));
+    YT_REQUIRE(nb <= 65535, "colsum: too many row blocks (%d)", nb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64), nb), dim3(256), 0, as_stream(stream), x, ldx, M, N, out, ldo,
+                       rows_per_block);
+    YT_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+extern "C" int ytvln_colsum_by_index_f32(const float* x, int64_t ldx, const float* idx_f32, int64_t idx_stride,
+                                         const int64_t* idx_i64, int M, int N, int KT, float* out, int rows_per_block,
+                                         void* stream) {
+    YT_REQUIRE(x && out && (idx_f32 || idx_i64), "colsum_by_index: null pointer");
+    YT_REQUIRE(KT > 0 && KT <= 32 && N > 0 && rows_per_block > 0, "colsum_by_index: KT=%d must be in 1..32", KT);
+    const int nb = (int)std::max<int64_t>(1, cdiv(M, rows_per_block));
+    YT_REQUIRE(nb <= 65535, "colsum_by_index: too many row blocks");
+    hipLaunchKernelGGL(colsum_by_index_kernel, dim3((unsigned)cdiv(N, 64), nb), dim3(256), (size_t)4 * KT * 64 * sizeof(float),
+                       as_stream(stream), x, ldx, idx_f32, idx_stride, idx_i64, M, N, KT, out, rows_per_block);
+    YT_LAUNCH_CHECK("colsum_by_index");
+    return 0;
+}
+
+extern "C" int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int M, int H, float* table_grad,
+                                          int64_t skip_idx, void* stream) {
+    YT_REQUIRE(x && idx && table_grad && H > 0, "scatter_add_rows: bad argument");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M, 4), 4096)), dim3(256), 0,
+                       as_stream(stream), x, ldx, idx, M, H, table_grad, skip_idx);
+    YT_LAUNCH_CHECK("scatter_add_rows");
+    return 0;
+}
+
+extern "C" int ytvln_act_bwd_f32(const float* dy, const float* aux, float* dz, int64_t n, int act, void* stream) {
+    YT_REQUIRE(dy && aux && dz, "act_bwd: null pointer");
+    YT_REQUIRE(act == YTVLN_EPI_GELU || act == YTVLN_EPI_RELU, "act_bwd: bad act %d", act);
+    YT_REQUIRE(al16(dy) && al16(aux) && al16(dz), "act_bwd: pointers must be 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4, 256), 4096))), dim3(256), 0,
+                       as_stream(stream), dy, aux, dz, n, act);
+    YT_LAUNCH_CHECK("act_bwd");
+    return 0;
+}
+
+extern "C" int ytvln_dropout_f32(const float* x, float* y, int64_t n, float p, const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(x && y && rng, "dropout: null pointer");
+    YT_REQUIRE(p >= 0.f && p < 1.f, "dropout: p out of range");
+    YT_REQUIRE(al16(x) && al16(y), "dropout: pointers must be 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4, 256), 4096))), dim3(256), 0,
+                       as_stream(stream), x, y, n, p, rng, site);
+    YT_LAUNCH_CHECK("dropout");
+    return 0;
+}

@@ -1,0 +1,91 @@
+"""ctypes binding of libytvln.so (the C ABI declared in include/ytvln.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved the import of the compute path
+fails loudly (`YtvlnLibraryError`).  `torch` is imported first on purpose so that the HIP runtime the library binds to
+(`libamdhip64.so.7`) is the one PyTorch already loaded -- streams and device pointers are then interchangeable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libytvln.so")
+
+
+class YtvlnLibraryError(RuntimeError):
+    pass
+
+
+P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+# name -> argtypes, exactly mirroring include/ytvln.h (tests/test_abi.py checks header <-> table <-> exported symbols)
+SIGNATURES = {
+    "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P],
+    "ytvln_colsum_f32": [P, I64, I32, I32, P, I64, I32, P],
+    "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
+    "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],
+    "ytvln_ln_fwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],
+    "ytvln_ln_bwd_blocks": [I64],
+    "ytvln_ln_bwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, I64, P],
+    "ytvln_text_embed_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, P, I64, P],
+    "ytvln_image_embed_fwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, I64, P],
+    "ytvln_act_bwd_f32": [P, P, P, I64, I32, P],
+    "ytvln_dropout_f32": [P, P, I64, F32, P, I64, P],
+    "ytvln_attn_fwd_f32": [P, I64, P, I64, P, I64, P, P, I64, P, I32, I32, I32, I32, I32, F32, F32, P, I64, P],
+    "ytvln_attn_bwd_f32": [P, I64, P, I64, P, I64, P, P, P, I64, P, P, P, I64, P, I64, P, I64, I32, I32, I32, I32, I32,
+                           F32, F32, P, I64, P],
+    "ytvln_attn_probs_f32": [P, I64, P, I64, P, P, P, I32, I32, I32, I32, I32, F32, P],
+    "ytvln_ce_fwd_f32": [P, I64, P, I64, P, P, P, I32, I32, P],
+    "ytvln_ce_bwd_f32": [P, I64, P, I64, P, P, P, P, I64, I32, I32, P],
+    "ytvln_kl_fwd_f32": [P, I64, P, I64, P, P, P, P, I32, I32, P],
+    "ytvln_kl_bwd_f32": [P, I64, P, I64, P, P, P, P, P, I64, I32, I32, P],
+    "ytvln_bce_fwd_f32": [P, P, P, P, I32, P],
+    "ytvln_bce_bwd_f32": [P, P, P, P, P, I32, P],
+    "ytvln_adamw_f32": [P, P, P, P, P, I32, P, F32, P],
+}
+
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
+ABI_VERSION = 1
+
+_lib = None
+
+
+def load():
+    """dlopen the library once, bind every symbol, verify the ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YtvlnLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU / PyTorch fallback for the compute path).")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise YtvlnLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    lib.ytvln_version.restype = I32
+    lib.ytvln_version.argtypes = []
+    lib.ytvln_last_error.restype = C.c_char_p
+    lib.ytvln_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise YtvlnLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = I32
+    if lib.ytvln_version() != ABI_VERSION:
+        raise YtvlnLibraryError(f"ABI mismatch: library {lib.ytvln_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Invoke an entry point; non-zero status -> RuntimeError carrying ytvln_last_error()."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.ytvln_last_error().decode(errors='replace')}")

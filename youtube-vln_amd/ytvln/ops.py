@@ -1,0 +1,599 @@
+"""torch.autograd.Function wrappers over the C ABI (include/ytvln.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd graph; every FLOP / byte of the hot path runs in
+libytvln.so.  All wrappers require CUDA(HIP) fp32 tensors -- there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EPI_GELU, EPI_MUL_DGELU, EPI_NONE, EPI_RELU, call
+
+Tensor = torch.Tensor
+_ACT = {"none": EPI_NONE, None: EPI_NONE, "gelu": EPI_GELU, "relu": EPI_RELU}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plumbing helpers
+# ------------------------------------------------------------------------------------------------------------------
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor], offset_elems: int = 0):
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * offset_elems
+
+
+def _check(t: Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError(f"ytvln.ops: `{name}` must live on the GPU (no CPU fallback); got device {t.device}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"ytvln.ops: `{name}` must be {dtype}; got {t.dtype}")
+
+
+def _rows2d(x: Tensor, name: str) -> Tuple[Tensor, int, int, int]:
+    """View x as [M, K] rows with unit inner stride; returns (tensor-keeping-storage, M, K, leading dimension)."""
+    _check(x, name)
+    K = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K:
+        return x, x.shape[0], K, x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x, x.numel() // max(K, 1), K, K
+
+
+def _i64(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"ytvln.ops: `{name}` must live on the GPU")
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dropout RNG state: (seed, forward counter) in device memory + host-side site ids
+# ------------------------------------------------------------------------------------------------------------------
+class DropoutState:
+    """Philox key material for one forward pass.  `tensor` is an int64[2] DEVICE tensor (seed, counter) that the kernels
+    read; every dropout site of the pass takes the next `site` id.  Backward regenerates masks from (tensor, site)."""
+
+    _global = {}
+    seed = 0x5EED
+
+    def __init__(self, device):
+        g = DropoutState._global.get(device)
+        if g is None:
+            g = torch.tensor([DropoutState.seed, 0], dtype=torch.int64, device=device)
+            DropoutState._global[device] = g
+        self.tensor = g.clone()          # frozen copy for this forward (and its backward)
+        g[1] += 1                        # device-side increment: graph-capturable, no host sync
+        self._site = 0
+
+    def next_site(self) -> int:
+        self._site += 1
+        return self._site
+
+    @classmethod
+    def manual_seed(cls, seed: int):
+        cls.seed = int(seed)
+        cls._global.clear()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GEMM primitives
+# ------------------------------------------------------------------------------------------------------------------
+def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0):
+    call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
+         M, N, K, epi, float(beta), _stream())
+
+
+def colsum(x: Tensor, M: int, N: int, ld: int) -> Tensor:
+    """Deterministic column sums of the [M, N] matrix at x (leading dimension ld) -> [N]."""
+    while True:
+        nstrips = (N + 63) // 64
+        nb = max(1, min((M + 31) // 32, max(1, 2048 // nstrips)))
+        rpb = (M + nb - 1) // nb
+        nb = (M + rpb - 1) // rpb
+        out = torch.empty((nb, N), dtype=torch.float32, device=x.device)
+        call("ytvln_colsum_f32", _ptr(x), ld, M, N, _ptr(out), N, rpb, _stream())
+        if nb == 1:
+            return out[0]
+        x, M, ld = out, nb, N
+
+
+def colsum_by_index(x: Tensor, M: int, N: int, ld: int, KT: int, idx_f32: Optional[Tensor] = None, idx_stride: int = 1,
+                    idx_f32_offset: int = 0, idx_i64: Optional[Tensor] = None) -> Tensor:
+    """out[k, n] = sum of rows r with idx[r] == k -> [KT, N] (KT <= 32)."""
+    nstrips = (N + 63) // 64
+    nb = max(1, min((M + 31) // 32, max(1, 1024 // nstrips)))
+    rpb = (M + nb - 1) // nb
+    nb = (M + rpb - 1) // rpb
+    out = torch.empty((nb, KT, N), dtype=torch.float32, device=x.device)
+    call("ytvln_colsum_by_index_f32", _ptr(x), ld, _ptr(idx_f32, idx_f32_offset) if idx_f32 is not None else None, idx_stride,
+         _ptr(idx_i64) if idx_i64 is not None else None, M, N, KT, _ptr(out), rpb, _stream())
+    if nb == 1:
+        return out[0]
+    return colsum(out, nb, KT * N, KT * N).view(KT, N)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b)  -- nn.Linear + optional erf-GELU / ReLU epilogue, all on the fp32 MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x2, M, K, lda = _rows2d(x, "x")
+        _check(weight, "weight")
+        if weight.stride(-1) != 1:
+            weight = weight.contiguous()
+        N = weight.shape[0]
+        assert weight.shape[1] == K, (weight.shape, K)
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        epi = _ACT[act]
+        z = torch.empty_like(y) if (epi == EPI_GELU and need_grad) else None
+        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, N, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
+        ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
+        ctx.in_shape = x.shape
+        ctx.save_for_backward(x2, weight, z if epi == EPI_GELU else (y if epi == EPI_RELU else None))
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, aux = ctx.saved_tensors
+        M, N, K = ctx.dims
+        dy = dy.reshape(M, N)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        if ctx.epi != EPI_NONE:
+            dz = torch.empty_like(dy)
+            call("ytvln_act_bwd_f32", _ptr(dy), _ptr(aux), _ptr(dz), dy.numel(), ctx.epi, _stream())
+            dy = dz
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _gemm(dy, N, 0, weight, weight.stride(0), 0, dx, K, M, K, N)
+            dx = dx.view(ctx.in_shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            _gemm(dy, N, 1, x2, ctx.lda, 0, dw, K, N, K, M)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, N, N)
+        return dx, dw, db, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tensor:
+    return LinearFn.apply(x, weight, bias, act)
+
+
+class FFNFn(torch.autograd.Function):
+    """out = gelu(x W1^T + b1) W2^T + b2   (BertIntermediate + BertOutput.dense, vilbert.py:351-354, 365).
+    Backward fuses the GELU derivative into the epilogue of the dX GEMM of the second projection."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2, M, K, lda = _rows2d(x, "x")
+        I, N = w1.shape[0], w2.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        h = torch.empty((M, I), dtype=torch.float32, device=x.device)
+        z = torch.empty_like(h) if need_grad else None
+        _gemm(x2, lda, 0, w1, w1.stride(0), 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU)
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2)
+        ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
+        ctx.save_for_backward(x2, w1, w2, z, h)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, z, h = ctx.saved_tensors
+        M, K, I, N = ctx.dims
+        dy = dy.reshape(M, N)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dev = dy.device
+        dz = torch.empty((M, I), dtype=torch.float32, device=dev)
+        _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU)   # dH * gelu'(z)
+        dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
+        _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M)
+        db2 = colsum(dy, M, N, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I)
+            dx = dx.view(ctx.in_shape)
+        dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
+        _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M)
+        db1 = colsum(dz, M, I, I)
+        return dx, dw1, db1, dw2, db2
+
+
+def ffn(x, w1, b1, w2, b2) -> Tensor:
+    return FFNFn.apply(x, w1, b1, w2, b2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LayerNorm family
+# ------------------------------------------------------------------------------------------------------------------
+def _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site):
+    dy = dy.reshape(rows, H)
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    ds = torch.empty((rows, H), dtype=torch.float32, device=dy.device)
+    dx = torch.empty_like(ds) if p_pre > 0 else None
+    nb = _lib.load().ytvln_ln_bwd_blocks(rows)
+    partial = torch.empty((nb, 2 * H), dtype=torch.float32, device=dy.device)
+    call("ytvln_ln_bwd_f32", _ptr(dy), _ptr(s), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(ds), _ptr(dx), _ptr(partial), rows, H,
+         float(p_pre), float(p_post), _ptr(rng) if rng is not None else None, int(site), _stream())
+    gb = colsum(partial, nb, 2 * H, 2 * H)
+    return ds, (dx if dx is not None else ds), gb[:H], gb[H:]
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """y = LN(dropout(x) + residual) [dropout after] -- BertLayerNorm with its surrounding dropout / residual add."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p_pre, p_post, rng, site):
+        _check(x, "x")
+        H = x.shape[-1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        rc = None
+        if res is not None:
+            rc = res if res.is_contiguous() else res.contiguous()
+        rows = xc.numel() // H
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(xc)
+        s = torch.empty_like(xc) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        rstd = torch.empty_like(mean) if need_grad else None
+        call("ytvln_ln_fwd_f32", _ptr(xc), _ptr(rc), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s), _ptr(mean), _ptr(rstd), rows, H,
+             float(eps), float(p_pre), float(p_post), _ptr(rng) if rng is not None else None, int(site), _stream())
+        ctx.meta = (rows, H, p_pre, p_post, site, res is not None)
+        ctx.save_for_backward(s, mean, rstd, gamma, rng)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, mean, rstd, gamma, rng = ctx.saved_tensors
+        rows, H, p_pre, p_post, site, has_res = ctx.meta
+        ds, dx, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site)
+        shape = dy.shape
+        return (dx.view(shape) if ctx.needs_input_grad[0] else None,
+                ds.view(shape) if (has_res and ctx.needs_input_grad[1]) else None, dg, db, None, None, None, None, None)
+
+
+def add_layer_norm(x, res, gamma, beta, eps=1e-12, p_pre=0.0, p_post=0.0, drop: Optional[DropoutState] = None) -> Tensor:
+    if (p_pre > 0 or p_post > 0) and drop is None:
+        raise RuntimeError("dropout requested without a DropoutState")
+    use = drop is not None and (p_pre > 0 or p_post > 0)
+    return AddLayerNormFn.apply(x, res, gamma, beta, eps, p_pre if use else 0.0, p_post if use else 0.0,
+                                drop.tensor if use else None, drop.next_site() if use else 0)
+
+
+class TextEmbedFn(torch.autograd.Function):
+    """BertEmbeddings.forward (vilbert.py:240-256) fused: gather x3 + add + LayerNorm + dropout."""
+
+    @staticmethod
+    def forward(ctx, ids, type_ids, word, pos, typ, gamma, beta, eps, p_post, rng, site):
+        ids = _i64(ids, "input_ids")
+        N, T = ids.shape
+        H = word.shape[1]
+        if T > pos.shape[0]:
+            raise RuntimeError(f"sequence length {T} exceeds max_position_embeddings {pos.shape[0]}")
+        tt = _i64(type_ids, "token_type_ids") if type_ids is not None else None
+        rows = N * T
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty((N, T, H), dtype=torch.float32, device=word.device)
+        s = torch.empty_like(y) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=word.device) if need_grad else None
+        rstd = torch.empty_like(mean) if need_grad else None
+        call("ytvln_text_embed_fwd_f32", _ptr(ids), _ptr(tt), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma), _ptr(beta), _ptr(y),
+             _ptr(s), _ptr(mean), _ptr(rstd), rows, T, H, float(eps), float(p_post), _ptr(rng) if rng is not None else None,
+             int(site), _stream())
+        ctx.meta = (N, T, H, p_post, site, word.shape, pos.shape, typ.shape)
+        ctx.save_for_backward(ids, tt, s, mean, rstd, gamma, rng)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, tt, s, mean, rstd, gamma, rng = ctx.saved_tensors
+        N, T, H, p_post, site, wshape, pshape, tshape = ctx.meta
+        rows = N * T
+        ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
+        dev = ds.device
+        dword = torch.zeros(wshape, dtype=torch.float32, device=dev)
+        call("ytvln_scatter_add_rows_f32", _ptr(ds), H, _ptr(ids), rows, H, _ptr(dword), 0, _stream())   # padding_idx = 0
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=dev)
+        dpos[:T] = colsum(ds, N, T * H, T * H).view(T, H)
+        if tt is None:
+            dtyp = torch.zeros(tshape, dtype=torch.float32, device=dev)
+            dtyp[0] = colsum(ds, rows, H, H)
+        elif tshape[0] <= 32:
+            dtyp = colsum_by_index(ds, rows, H, H, tshape[0], idx_i64=tt)
+        else:
+            dtyp = torch.zeros(tshape, dtype=torch.float32, device=dev)
+            call("ytvln_scatter_add_rows_f32", _ptr(ds), H, _ptr(tt), rows, H, _ptr(dtyp), -1, _stream())
+        return None, None, dword, dpos, dtyp, dg, db, None, None, None, None
+
+
+def text_embed(ids, type_ids, word, pos, typ, gamma, beta, eps=1e-12, p=0.0, drop: Optional[DropoutState] = None) -> Tensor:
+    use = drop is not None and p > 0
+    return TextEmbedFn.apply(ids, type_ids, word, pos, typ, gamma, beta, eps, p if use else 0.0, drop.tensor if use else None,
+                             drop.next_site() if use else 0)
+
+
+class ImageEmbedFn(torch.autograd.Function):
+    """BertImageEmbeddings.forward after the feature projection (vilbert.py:1361-1368), fused:
+    location / orientation / next-orientation linears (K = 5, 4, 2) + frame-index gather + add + LayerNorm + dropout."""
+
+    @staticmethod
+    def forward(ctx, img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps, p_post, rng, site):
+        _check(img, "img")
+        _check(loc, "image_loc")
+        H = img.shape[-1]
+        imgc = img if img.is_contiguous() else img.contiguous()
+        locc = loc if loc.is_contiguous() else loc.contiguous()
+        if locc.shape[-1] != 12:
+            raise RuntimeError(f"image_loc must have 12 columns (5 box + 4 orientation + 2 next-orientation + frame); got {locc.shape}")
+        rows = imgc.numel() // H
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(imgc)
+        s = torch.empty_like(imgc) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=img.device) if need_grad else None
+        rstd = torch.empty_like(mean) if need_grad else None
+        ws = [w if w.is_contiguous() else w.contiguous() for w in (W5, W4, W2, E)]
+        call("ytvln_image_embed_fwd_f32", _ptr(imgc), _ptr(locc), _ptr(ws[0]), _ptr(b5), _ptr(ws[1]), _ptr(b4), _ptr(ws[2]), _ptr(b2),
+             _ptr(ws[3]), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s), _ptr(mean), _ptr(rstd), rows, H, float(eps), float(p_post),
+             _ptr(rng) if rng is not None else None, int(site), _stream())
+        ctx.meta = (rows, H, p_post, site, E.shape[0])
+        ctx.save_for_backward(locc, s, mean, rstd, gamma, rng)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        locc, s, mean, rstd, gamma, rng = ctx.saved_tensors
+        rows, H, p_post, site, KT = ctx.meta
+        ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
+        dev = ds.device
+        dwall = torch.empty((H, 12), dtype=torch.float32, device=dev)
+        _gemm(ds, H, 1, locc, 12, 0, dwall, 12, H, 12, rows)               # ds^T . loc  -> [H, 12]
+        dbias = colsum(ds, rows, H, H)
+        dE = colsum_by_index(ds, rows, H, H, KT, idx_f32=locc, idx_stride=12, idx_f32_offset=11)
+        return (ds.view(dy.shape), None, dwall[:, 0:5].contiguous(), dbias, dwall[:, 5:9].contiguous(), dbias,
+                dwall[:, 9:11].contiguous(), dbias, dE, dg, db, None, None, None, None)
+
+
+def image_embed(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps=1e-12, p=0.0, drop: Optional[DropoutState] = None) -> Tensor:
+    use = drop is not None and p > 0
+    return ImageEmbedFn.apply(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps, p if use else 0.0,
+                              drop.tensor if use else None, drop.next_site() if use else 0)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, rng, site):
+        _check(x, "x")
+        xc = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(xc)
+        call("ytvln_dropout_f32", _ptr(xc), _ptr(y), xc.numel(), float(p), _ptr(rng), int(site), _stream())
+        ctx.p, ctx.site = p, site
+        ctx.save_for_backward(rng)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rng,) = ctx.saved_tensors
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dyc)
+        call("ytvln_dropout_f32", _ptr(dyc), _ptr(dx), dyc.numel(), float(ctx.p), _ptr(rng), int(ctx.site), _stream())
+        return dx, None, None, None
+
+
+def dropout(x: Tensor, p: float, training: bool, drop: Optional[DropoutState]) -> Tensor:
+    if not training or p <= 0.0:
+        return x
+    if drop is None:
+        raise RuntimeError("dropout requested without a DropoutState")
+    return DropoutFn.apply(x, p, drop.tensor, drop.next_site())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------------
+def _attn_fwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, N, heads, Tq, Tk, d, scale, p, rng, site):
+    lse = torch.empty((N, heads, Tq), dtype=torch.float32, device=out.device)
+    call("ytvln_attn_fwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), out.shape[-1],
+         _ptr(lse), N, heads, Tq, Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
+    return lse
+
+
+def _attn_bwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, dout, lse, dq, dq_off, lddq, dk, dk_off, lddk, dv, dv_off,
+              lddv, N, heads, Tq, Tk, d, scale, p, rng, site):
+    delta = torch.empty_like(lse)
+    call("ytvln_attn_bwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), _ptr(dout),
+         out.shape[-1], _ptr(lse), _ptr(delta), _ptr(dq, dq_off), lddq, _ptr(dk, dk_off), lddk, _ptr(dv, dv_off), lddv, N, heads, Tq,
+         Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
+
+
+def attn_probs(q, q_off, ldq, k, k_off, ldk, mask, lse, N, heads, Tq, Tk, d, scale) -> Tensor:
+    probs = torch.empty((N, heads, Tq, Tk), dtype=torch.float32, device=lse.device)
+    call("ytvln_attn_probs_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(mask), _ptr(lse), _ptr(probs), N, heads, Tq, Tk, d,
+         float(scale), _stream())
+    return probs
+
+
+class SelfAttentionFn(torch.autograd.Function):
+    """ctx = MHA(qkv) for a packed [N*T, 3H] projection (query | key | value column blocks); vilbert.py:284-311."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, N, T, heads, p, rng, site):
+        _check(qkv, "qkv")
+        assert qkv.is_contiguous() and qkv.dim() == 2 and qkv.shape[0] == N * T
+        H = qkv.shape[1] // 3
+        d = H // heads
+        scale = 1.0 / math.sqrt(d)
+        out = torch.empty((N * T, H), dtype=torch.float32, device=qkv.device)
+        lse = _attn_fwd(qkv, 0, 3 * H, qkv, H, 3 * H, qkv, 2 * H, 3 * H, mask, out, N, heads, T, T, d, scale, p, rng, site)
+        ctx.meta = (N, T, heads, H, d, scale, p, site)
+        ctx.save_for_backward(qkv, mask, out, lse, rng)
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        qkv, mask, out, lse, rng = ctx.saved_tensors
+        N, T, heads, H, d, scale, p, site = ctx.meta
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        _attn_bwd(qkv, 0, 3 * H, qkv, H, 3 * H, qkv, 2 * H, 3 * H, mask, out, dout, lse, dqkv, 0, 3 * H, dqkv, H, 3 * H, dqkv, 2 * H,
+                  3 * H, N, heads, T, T, d, scale, p, rng, site)
+        return dqkv, None, None, None, None, None, None, None
+
+
+class CoAttentionFn(torch.autograd.Function):
+    """BertBiAttention (vilbert.py:552-618) on packed projections.  qkv1 [N*R, 3Hb] from the image stream
+    (query1|key1|value1), qkv2 [N*T, 3Hb] from the text stream (query2|key2|value2).
+    ctx1 [N*T, Hb] = text queries over image keys/values (mask1 = image mask);
+    ctx2 [N*R, Hb] = image queries over text keys/values (mask2 = text mask)."""
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, mask1, mask2, N, R, T, heads, p1, p2, rng, site1, site2):
+        _check(qkv1, "qkv1")
+        _check(qkv2, "qkv2")
+        assert qkv1.is_contiguous() and qkv2.is_contiguous()
+        Hb = qkv1.shape[1] // 3
+        d = Hb // heads
+        scale = 1.0 / math.sqrt(d)
+        L = 3 * Hb
+        ctx1 = torch.empty((N * T, Hb), dtype=torch.float32, device=qkv1.device)
+        ctx2 = torch.empty((N * R, Hb), dtype=torch.float32, device=qkv1.device)
+        lse1 = _attn_fwd(qkv2, 0, L, qkv1, Hb, L, qkv1, 2 * Hb, L, mask1, ctx1, N, heads, T, R, d, scale, p1, rng, site1)
+        lse2 = _attn_fwd(qkv1, 0, L, qkv2, Hb, L, qkv2, 2 * Hb, L, mask2, ctx2, N, heads, R, T, d, scale, p2, rng, site2)
+        ctx.meta = (N, R, T, heads, Hb, d, scale, p1, p2, site1, site2)
+        ctx.save_for_backward(qkv1, qkv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng)
+        ctx.mark_non_differentiable(lse1, lse2)
+        return ctx1, ctx2, lse1, lse2
+
+    @staticmethod
+    def backward(ctx, d1, d2, _a, _b):
+        qkv1, qkv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng = ctx.saved_tensors
+        N, R, T, heads, Hb, d, scale, p1, p2, site1, site2 = ctx.meta
+        L = 3 * Hb
+        d1 = d1 if d1.is_contiguous() else d1.contiguous()
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        g1, g2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
+        # direction 1: q = query2 (text), k/v = key1/value1 (image)  -> dq2, dk1, dv1
+        _attn_bwd(qkv2, 0, L, qkv1, Hb, L, qkv1, 2 * Hb, L, mask1, ctx1, d1, lse1, g2, 0, L, g1, Hb, L, g1, 2 * Hb, L, N, heads, T, R,
+                  d, scale, p1, rng, site1)
+        # direction 2: q = query1 (image), k/v = key2/value2 (text)  -> dq1, dk2, dv2
+        _attn_bwd(qkv1, 0, L, qkv2, Hb, L, qkv2, 2 * Hb, L, mask2, ctx2, d2, lse2, g1, 0, L, g2, Hb, L, g2, 2 * Hb, L, N, heads, R, T,
+                  d, scale, p2, rng, site2)
+        return (g1, g2) + (None,) * 11
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------------------------
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits, target, ignore_index) with mean reduction (utils_init.py:133-135, :141)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        lg, M, V, ld = _rows2d(logits, "logits")
+        tg = _i64(target, "target").reshape(-1)
+        assert tg.numel() == M, (tg.shape, M)
+        dev = lg.device
+        row_lse = torch.empty(M, dtype=torch.float32, device=dev)
+        row_loss = torch.empty(M, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        call("ytvln_ce_fwd_f32", _ptr(lg), ld, _ptr(tg), int(ignore_index), _ptr(row_lse), _ptr(row_loss), _ptr(out), M, V, _stream())
+        ctx.meta = (M, V, ld, int(ignore_index), logits.shape)
+        ctx.save_for_backward(lg, tg, row_lse, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, tg, row_lse, out = ctx.saved_tensors
+        M, V, ld, ign, shape = ctx.meta
+        g = g.reshape(1).contiguous().float()
+        dl = torch.empty((M, V), dtype=torch.float32, device=lg.device)
+        call("ytvln_ce_bwd_f32", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dl), V, M, V, _stream())
+        return dl.view(shape), None, None
+
+
+def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:
+    return CrossEntropyFn.apply(logits, target, ignore_index)
+
+
+class KLMaskedFn(torch.autograd.Function):
+    """sum(mask * kl_div(log_softmax(pred), target)) / max(1, sum(mask))  (utils_init.py:117-128), no host sync."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        pr, M, Cc, ld = _rows2d(pred, "pred")
+        tg, M2, C2, ldt = _rows2d(target, "target")
+        assert (M, Cc) == (M2, C2), (pred.shape, target.shape)
+        mk = _i64(mask, "mask").reshape(-1)
+        dev = pr.device
+        row_lse = torch.empty(M, dtype=torch.float32, device=dev)
+        row_loss = torch.empty(M, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        call("ytvln_kl_fwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(row_loss), _ptr(out), M, Cc, _stream())
+        ctx.meta = (M, Cc, ld, ldt, pred.shape)
+        ctx.save_for_backward(pr, tg, mk, row_lse, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pr, tg, mk, row_lse, out = ctx.saved_tensors
+        M, Cc, ld, ldt, shape = ctx.meta
+        g = g.reshape(1).contiguous().float()
+        dp = torch.empty((M, Cc), dtype=torch.float32, device=pr.device)
+        call("ytvln_kl_bwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dp), Cc, M, Cc, _stream())
+        return dp.view(shape), None, None
+
+
+def kl_masked(pred: Tensor, target: Tensor, mask: Tensor) -> Tensor:
+    return KLMaskedFn.apply(pred, target, mask)
+
+
+class BCEWithLogitsFn(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(x, t, pos_weight=w), mean reduction (utils_init.py:143, :160-161)."""
+
+    @staticmethod
+    def forward(ctx, x, t, pos_weight):
+        _check(x, "x")
+        xc = x.contiguous()
+        tc = t.to(torch.float32).contiguous()
+        pw = pos_weight.to(torch.float32).reshape(1).contiguous() if pos_weight is not None else None
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        call("ytvln_bce_fwd_f32", _ptr(xc), _ptr(tc), _ptr(pw), _ptr(out), xc.numel(), _stream())
+        ctx.save_for_backward(xc, tc, pw)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, tc, pw = ctx.saved_tensors
+        g = g.reshape(1).contiguous().float()
+        dx = torch.empty_like(xc)
+        call("ytvln_bce_bwd_f32", _ptr(xc), _ptr(tc), _ptr(pw), _ptr(g), _ptr(dx), xc.numel(), _stream())
+        return dx, None, None
+
+
+def bce_with_logits(x: Tensor, t: Tensor, pos_weight: Optional[Tensor] = None) -> Tensor:
+    return BCEWithLogitsFn.apply(x, t, pos_weight)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# optimizer kernel
+# ------------------------------------------------------------------------------------------------------------------
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, chunks: Tensor, nchunks: int, hyper: Tensor, grad_scale: float = 1.0):
+    for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyper, "hyper")):
+        _check(t, nme)
+    call("ytvln_adamw_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), chunks.data_ptr(), int(nchunks), _ptr(hyper), float(grad_scale),
+         _stream())

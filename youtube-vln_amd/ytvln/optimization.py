@@ -1,0 +1,207 @@
+"""Fused AdamW + LR schedules with the reference's semantics (`vilbert/optimization.py`).
+
+`AdamW` keeps the reference constructor (`AdamW(params, lr, betas, eps, weight_decay, correct_bias)`), the per-parameter
+state layout (`step`, `exp_avg`, `exp_avg_sq` -> checkpoints stay interchangeable) and its exact update rule
+(`optimization.py:141-187`: denom = sqrt(v)+eps, bias correction folded into the step size, decoupled decay applied AFTER
+the update, tensors without a gradient skipped entirely).  Execution differs: on the first `step()` the parameters that
+received a gradient are moved into one flat fp32 arena (their `.data` / `.grad` become views), moments live in two more
+arenas, and a whole step is one HIP kernel launch per (param-group, step-count) class instead of ~8 ATen kernels per
+tensor x 541 tensors.  The flat gradient arena is also what the data-parallel all-reduce buckets (ytvln/distributed.py).
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import Dict, List
+
+import torch
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import ops
+
+CHUNK = 16384       # elements per workgroup of the fused kernel
+ALIGN = 4           # arena offsets are multiples of 4 floats (16-byte vector access)
+
+
+class ConstantLRSchedule(LambdaLR):
+    """optimization.py:26-30."""
+
+    def __init__(self, optimizer, last_epoch=-1):
+        super().__init__(optimizer, lambda _: 1.0, last_epoch=last_epoch)
+
+
+class WarmupConstantSchedule(LambdaLR):
+    """optimization.py:33-45."""
+
+    def __init__(self, optimizer, warmup_steps, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1.0, self.warmup_steps))
+        return 1.0
+
+
+class WarmupLinearSchedule(LambdaLR):
+    """optimization.py:48-61: linear warm-up to 1 over `warmup_steps`, then linear decay to 0 at `t_total`."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        self.t_total = t_total
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
+
+
+class AdamW(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+        self._arena = None          # dict(p, g, m, v flat tensors; index: id(param) -> (offset, numel))
+        self._launch = None         # list of launch classes
+        self.grad_scale = 1.0       # multiplied into the gradient inside the kernel (set by data-parallel wrappers)
+
+    # ---- arena management -----------------------------------------------------------------------------------------
+    def _members(self):
+        return [(gi, p) for gi, g in enumerate(self.param_groups) for p in g["params"] if p.grad is not None]
+
+    def flat_grads(self):
+        """The flat gradient arena (None before the first step): what a data-parallel wrapper all-reduces."""
+        return None if self._arena is None else self._arena["g"]
+
+    def arena_layout(self) -> Dict[int, tuple]:
+        return {} if self._arena is None else dict(self._arena["index"])
+
+    def _build_arena(self, members):
+        dev = members[0][1].device
+        for _, p in members:
+            if p.dtype != torch.float32 or not p.is_cuda:
+                raise RuntimeError("ytvln AdamW needs fp32 parameters on a HIP device (no CPU fallback)")
+            if p.grad.is_sparse:
+                raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+        old = self._arena
+        index, off = {}, 0
+        for _, p in members:
+            index[id(p)] = (off, p.numel())
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        flat = {k: torch.zeros(off, dtype=torch.float32, device=dev) for k in ("p", "g", "m", "v")}
+        with torch.no_grad():
+            for _, p in members:
+                o, n = index[id(p)]
+                flat["p"][o:o + n].copy_(p.data.reshape(-1))
+                flat["g"][o:o + n].copy_(p.grad.reshape(-1))
+                st = self.state[p]
+                if "exp_avg" in st:                      # carried over from a previous arena / a loaded checkpoint
+                    flat["m"][o:o + n].copy_(st["exp_avg"].reshape(-1))
+                    flat["v"][o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                else:
+                    st["step"] = 0
+                p.data = flat["p"][o:o + n].view(p.shape)
+                p.grad = flat["g"][o:o + n].view(p.shape)
+                st["exp_avg"] = flat["m"][o:o + n].view(p.shape)
+                st["exp_avg_sq"] = flat["v"][o:o + n].view(p.shape)
+        self._arena = dict(flat, index=index, ids=[id(p) for _, p in members])
+        self._launch = None
+        del old
+
+    def _ensure_arena(self):
+        members = self._members()
+        if not members:
+            return members
+        if self._arena is None or self._arena["ids"] != [id(p) for _, p in members]:
+            self._build_arena(members)
+            return members
+        fp, fg, index = self._arena["p"], self._arena["g"], self._arena["index"]
+        base_p, base_g = fp.data_ptr(), fg.data_ptr()
+        stale_data = False
+        with torch.no_grad():
+            for _, p in members:
+                o, n = index[id(p)]
+                if p.data_ptr() != base_p + 4 * o:
+                    stale_data = True
+                    break
+                if p.grad.data_ptr() != base_g + 4 * o:       # e.g. model.zero_grad() dropped the views: re-adopt
+                    fg[o:o + n].copy_(p.grad.reshape(-1))
+                    p.grad = fg[o:o + n].view(p.shape)
+        if stale_data:                                         # parameters were re-allocated (model.to(...)): rebuild
+            self._build_arena(members)
+        return members
+
+    def _build_launch(self, members):
+        classes: Dict[tuple, list] = {}
+        for gi, p in members:
+            classes.setdefault((gi, self.state[p]["step"]), []).append(p)
+        index, dev = self._arena["index"], self._arena["p"].device
+        launch = []
+        for (gi, step), plist in classes.items():
+            wd = float(self.param_groups[gi]["weight_decay"])
+            rec = bytearray()
+            n = 0
+            for p in plist:
+                o, numel = index[id(p)]
+                for c in range(0, numel, CHUNK):
+                    rec += struct.pack("<qqff", o + c, min(CHUNK, numel - c), wd, 0.0)
+                    n += 1
+            table = torch.frombuffer(rec, dtype=torch.uint8).to(dev)
+            # hyper-parameters travel through a small ring of pinned host buffers (async H2D, no per-step stream sync);
+            # an event per slot guards reuse should the host ever run a full ring ahead of the device.
+            launch.append(dict(group=gi, step=step, params=plist, table=table, n=n,
+                               hyper=torch.zeros(8, dtype=torch.float32, device=dev),
+                               ring=[torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(4)],
+                               events=[None] * 4, slot=0))
+        self._launch = launch
+
+    # ---- the step -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        members = self._ensure_arena()
+        if not members:
+            return loss
+        if self._launch is None or any(self.state[c["params"][0]]["step"] != c["step"] for c in self._launch):
+            self._build_launch(members)
+        a = self._arena
+        if getattr(self, "grad_sync", None) is not None:      # data-parallel gradient exchange (ytvln/distributed.py)
+            self.grad_sync(a["g"], [(p,) + a["index"][id(p)] for _, p in members])
+        for c in self._launch:
+            g = self.param_groups[c["group"]]
+            b1, b2 = g["betas"]
+            t = c["step"] + 1
+            step_size = g["lr"]
+            if g["correct_bias"]:
+                step_size = step_size * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            k = c["slot"] = (c["slot"] + 1) % 4
+            if c["events"][k] is not None:
+                c["events"][k].synchronize()
+            host = c["ring"][k]
+            host[0], host[1], host[2], host[3], host[4] = b1, b2, g["eps"], step_size, g["lr"]
+            c["hyper"].copy_(host, non_blocking=True)
+            c["events"][k] = torch.cuda.Event()
+            c["events"][k].record()
+            ops.adamw_step(a["p"], a["g"], a["m"], a["v"], c["table"], c["n"], c["hyper"], self.grad_scale)
+            c["step"] = t
+            for p in c["params"]:
+                self.state[p]["step"] = t
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the flat gradient arena with one memset and keep the views (set_to_none would drop them and cost a
+        re-adoption copy at the next step).  Before the arena exists, behaves like torch's default."""
+        if self._arena is None or set_to_none:
+            return super().zero_grad(set_to_none=True)
+        self._arena["g"].zero_()

@@ -1,0 +1,182 @@
+"""Batch parsing, the four losses and the training-step body with the reference's semantics (`utils/utils_init.py`).
+
+`get_model_input` / `get_loss_correct` / `compute_metrics_independent` / `train_epoch` keep the reference names and
+argument order.  Differences are internal only: the big reductions (30522-way CE, 1601-way masked KL) and the small ones
+run on the fused loss kernels, and nothing calls `.item()` inside the step (the reference syncs at utils_init.py:127).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def pad_packed(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """utils/dataset/common.py:21-26: scatter the packed [N] scores back to [bs, K], -inf where opt_mask is False."""
+    mask = mask.bool()
+    out = torch.full(mask.shape, -float("inf"), dtype=t.dtype, device=t.device)
+    out[mask] = t
+    return out
+
+
+def get_model_input(batch, all_options=None):
+    """utils_init.py:34-77: unpack the 16-tuple, drop padded options with opt_mask, return Lily.forward's 9 positionals.
+
+    `all_options=True` (known on the host before the H2D copy, see train_epoch) means opt_mask has no holes: the
+    [bs, K, ...] tensors are then flattened as views instead of the reference's boolean-mask gather, which costs a
+    device->host sync (nonzero) plus a second copy of the region features."""
+    (_, image_features, image_locations, image_mask, _, _, instr_tokens, instr_mask, _, instr_highlights, segment_ids,
+     co_attention_mask, _, opt_mask, _, attend_order_visual_feature) = batch
+    if all_options is None:
+        all_options = (not opt_mask.is_cuda) and bool(opt_mask.all())
+    if all_options:
+        flat = lambda x: x.flatten(0, 1)      # noqa: E731
+    else:
+        flat = lambda x: x[opt_mask]          # noqa: E731
+    co_attention_mask = co_attention_mask.view(-1, co_attention_mask.size(2), co_attention_mask.size(3))
+    return (flat(instr_tokens), flat(image_features), flat(image_locations), flat(segment_ids), flat(instr_mask),
+            flat(image_mask), co_attention_mask, flat(instr_highlights), attend_order_visual_feature)
+
+
+def get_device(batch):
+    return batch[0].device
+
+
+def get_mask_options(batch) -> torch.Tensor:
+    return batch[13]
+
+
+def get_batch_size(batch):
+    return batch[1].size(0)
+
+
+def get_ranking_target(batch):
+    return batch[0]
+
+
+def get_vision_target(batch, all_options=False):
+    if all_options:
+        return batch[4].flatten(0, 2), batch[5].flatten()
+    opt_mask = get_mask_options(batch)
+    return batch[4][opt_mask].flatten(0, 1), batch[5][opt_mask].flatten()
+
+
+def get_linguistic_target(batch, all_options=False):
+    if all_options:
+        return batch[8].flatten()
+    return batch[8][get_mask_options(batch)].flatten()
+
+
+def get_loss_correct(batch: List[torch.Tensor], outputs: Dict[str, torch.Tensor], task, args, logger, training,
+                     all_options=False):
+    """utils_init.py:108-164 -> (batch_size, target, loss, correct).  `all_options`: see get_model_input."""
+    opt_mask = get_mask_options(batch)
+    unpack = (lambda t: t.view(opt_mask.shape)) if all_options else (lambda t: pad_packed(t, opt_mask))
+    batch_size = get_batch_size(batch)
+    device = opt_mask.device
+    correct = torch.tensor(0, device=device)
+    if task == "vision":
+        predictions = outputs["vision"]
+        predictions = predictions.reshape(-1, predictions.shape[2])
+        target, target_mask = get_vision_target(batch, all_options)
+        loss = ops.kl_masked(predictions, target.float(), target_mask)        # sum(KL*mask) / max(1, sum(mask)), on device
+    elif task == "language":
+        voc_size = outputs["language"].shape[-1]
+        target = get_linguistic_target(batch, all_options)
+        loss = ops.cross_entropy(outputs["language"].reshape(-1, voc_size), target, ignore_index=-1)
+    elif task == "ranking":
+        target = get_ranking_target(batch)
+        prediction = unpack(outputs["ranking"].squeeze(1))
+        if training:
+            loss = ops.cross_entropy(prediction, target, ignore_index=-1)
+            correct = torch.sum(torch.argmax(prediction, 1) == target).float()
+        else:
+            loss = ops.bce_with_logits(prediction, target.float())
+            correct = torch.sum(target.gather(1, torch.argmax(prediction, 1).view(-1, 1))).float()
+    elif task == "traj":
+        prediction = unpack(outputs["traj"].squeeze(1))
+        target = torch.zeros(prediction.shape, device=device).bool()
+        if not (args.ranking or args.not_traj_judge_data):
+            target[:, 0] = 1
+        elif args.pretrain:
+            target[:, :(1 + args.num_negatives)] = 1
+        else:
+            target[:, :-args.num_negatives] = 1
+        pos_weight = (target.shape[1] / target[0].sum() - 1).reshape(1).float()      # negatives / positives, stays on device
+        loss = ops.bce_with_logits(prediction, target.float(), pos_weight)
+        correct = torch.sum((prediction.sigmoid() > 0.5) == target).float() / target.shape[1]
+    else:
+        raise KeyError(task)
+    return batch_size, target, loss, correct
+
+
+def compute_metrics_independent(batch, outputs, task, args, logger, reduced_metrics, all_options=False) -> torch.Tensor:
+    """utils_init.py:167-189: loss for backward + (optionally all-reduced) logging copies."""
+    device = get_device(batch)
+    batch_size, target, loss, correct = get_loss_correct(batch, outputs, task, args, logger, True, all_options)
+    reduced_loss = loss.detach().float()
+    reduced_correct = correct.detach().float()
+    reduced_batch_size = torch.tensor(batch_size, device=device).float()
+    if getattr(args, "local_rank", -1) != -1 and not getattr(args, "skip_all_reduce", False) and dist.is_initialized():
+        packed = torch.stack([reduced_loss / float(dist.get_world_size()), reduced_correct, reduced_batch_size])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)          # one small collective instead of the reference's three
+        reduced_loss, reduced_correct, reduced_batch_size = packed[0], packed[1], packed[2]
+    reduced_metrics["loss"][task] = reduced_loss
+    if task not in ("vision", "language"):
+        reduced_metrics["accuracy"][task] = reduced_correct / reduced_batch_size
+    return loss
+
+
+TASKS = (("vision", "masked_vision"), ("language", "masked_language"), ("ranking", "ranking"), ("traj", "traj_judge"))
+
+
+def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=None, all_options=None):
+    """One iteration of train_epoch's body (utils_init.py:199-239): forward, loss composition in the reference's order,
+    backward, and -- every gradient_accumulation_steps -- optimizer.step(); scheduler.step(); zero_grad().
+    Returns (loss, reduced_metrics) as device tensors; never synchronises the host."""
+    outputs = model(*get_model_input(batch, all_options))
+    reduced_metrics = {"loss": {}, "accuracy": {}}
+    loss = None
+    for task, flag in TASKS:
+        if getattr(args, flag):
+            l = compute_metrics_independent(batch, outputs, task, args, logger, reduced_metrics, bool(all_options))
+            if task == "traj":
+                l = args.traj_loss_scale * l
+            loss = l if loss is None else loss + l
+    accum = getattr(args, "gradient_accumulation_steps", 1)
+    if accum > 1:
+        loss = loss / accum
+    loss.backward()
+    if (step + 1) % accum == 0:
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        if hasattr(optimizer, "_arena"):
+            optimizer.zero_grad()              # keeps the flat-arena views (one memset)
+        else:
+            model.zero_grad()
+    return loss.detach(), reduced_metrics
+
+
+def train_epoch(epoch, model, optimizer, scheduler, data_loader, writer, default_gpu, args, logger) -> None:
+    """utils_init.py:192-268.  Batches are moved to the model's device; scalars are only formatted (host sync) on the
+    logging rank, once per step, after the step has been queued."""
+    device = next(model.parameters()).device
+    model.train()
+    model.zero_grad()
+    for step, batch in enumerate(data_loader):
+        all_options = bool(batch[13].all()) if not batch[13].is_cuda else None      # decided on the host, no GPU sync
+        batch = tuple(t.to(device, non_blocking=True) if hasattr(t, "to") else t for t in batch)
+        loss, reduced_metrics = train_step(model, optimizer, scheduler, batch, args, step, logger, all_options)
+        if default_gpu and writer is not None:
+            global_step = step + epoch * len(data_loader)
+            total = sum(reduced_metrics["loss"].values())
+            writer.add_scalar("learning_rate/train", float(scheduler.get_last_lr()[0]), global_step=global_step)
+            writer.add_scalar("loss/train", float(total), global_step=global_step)
+            for task, item in reduced_metrics["accuracy"].items():
+                writer.add_scalar(f"accuracy/{task}", float(item), global_step=global_step)
+            for task, item in reduced_metrics["loss"].items():
+                writer.add_scalar(f"loss/{task}", float(item), global_step=global_step)
