@@ -127,6 +127,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
+        ctx.set_materialize_grads(False)
         x2, M, K, lda = _rows2d(x, "x")
         _check(weight, "weight")
         if weight.stride(-1) != 1:
@@ -145,6 +146,8 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None
         x2, weight, aux = ctx.saved_tensors
         M, N, K = ctx.dims
         dy = dy.reshape(M, N)
@@ -177,6 +180,7 @@ class FFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
+        ctx.set_materialize_grads(False)
         x2, M, K, lda = _rows2d(x, "x")
         I, N = w1.shape[0], w2.shape[0]
         need_grad = any(ctx.needs_input_grad)
@@ -191,6 +195,8 @@ class FFNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None, None
         x2, w1, w2, z, h = ctx.saved_tensors
         M, K, I, N = ctx.dims
         dy = dy.reshape(M, N)
@@ -239,6 +245,7 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, eps, p_pre, p_post, rng, site):
+        ctx.set_materialize_grads(False)
         _check(x, "x")
         H = x.shape[-1]
         xc = x if x.is_contiguous() else x.contiguous()
@@ -259,6 +266,8 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 9
         s, mean, rstd, gamma, rng = ctx.saved_tensors
         rows, H, p_pre, p_post, site, has_res = ctx.meta
         ds, dx, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site)
@@ -280,6 +289,7 @@ class TextEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, type_ids, word, pos, typ, gamma, beta, eps, p_post, rng, site):
+        ctx.set_materialize_grads(False)
         ids = _i64(ids, "input_ids")
         N, T = ids.shape
         H = word.shape[1]
@@ -301,6 +311,8 @@ class TextEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 11
         ids, tt, s, mean, rstd, gamma, rng = ctx.saved_tensors
         N, T, H, p_post, site, wshape, pshape, tshape = ctx.meta
         rows = N * T
@@ -333,6 +345,7 @@ class ImageEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps, p_post, rng, site):
+        ctx.set_materialize_grads(False)
         _check(img, "img")
         _check(loc, "image_loc")
         H = img.shape[-1]
@@ -356,6 +369,8 @@ class ImageEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 15
         locc, s, mean, rstd, gamma, rng = ctx.saved_tensors
         rows, H, p_post, site, KT = ctx.meta
         ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
@@ -377,6 +392,7 @@ def image_embed(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps=1e-12, p=0
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, rng, site):
+        ctx.set_materialize_grads(False)
         _check(x, "x")
         xc = x if x.is_contiguous() else x.contiguous()
         y = torch.empty_like(xc)
@@ -387,6 +403,8 @@ class DropoutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None
         (rng,) = ctx.saved_tensors
         dyc = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty_like(dyc)
@@ -432,6 +450,7 @@ class SelfAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, mask, N, T, heads, p, rng, site):
+        ctx.set_materialize_grads(False)
         _check(qkv, "qkv")
         assert qkv.is_contiguous() and qkv.dim() == 2 and qkv.shape[0] == N * T
         H = qkv.shape[1] // 3
@@ -446,6 +465,8 @@ class SelfAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dlse):
+        if dout is None:
+            return (None,) * 8
         qkv, mask, out, lse, rng = ctx.saved_tensors
         N, T, heads, H, d, scale, p, site = ctx.meta
         dout = dout if dout.is_contiguous() else dout.contiguous()
@@ -456,44 +477,47 @@ class SelfAttentionFn(torch.autograd.Function):
 
 
 class CoAttentionFn(torch.autograd.Function):
-    """BertBiAttention (vilbert.py:552-618) on packed projections.  qkv1 [N*R, 3Hb] from the image stream
-    (query1|key1|value1), qkv2 [N*T, 3Hb] from the text stream (query2|key2|value2).
-    ctx1 [N*T, Hb] = text queries over image keys/values (mask1 = image mask);
-    ctx2 [N*R, Hb] = image queries over text keys/values (mask2 = text mask)."""
+    """BertBiAttention (vilbert.py:552-618).  Projections are packed PER DIRECTION so that a direction whose context is
+    never used downstream (e.g. the vision side of the last co-layer under --masked_language only) propagates `None`
+    gradients exactly like the reference's autograd graph -- AdamW must not touch those tensors:
+        q1  [N*R, Hb]  = query1(image)        kv1 [N*R, 2Hb] = key1|value1(image)
+        q2  [N*T, Hb]  = query2(text)         kv2 [N*T, 2Hb] = key2|value2(text)
+        ctx1 [N*T, Hb] = attend(q2; kv1, image mask)     ctx2 [N*R, Hb] = attend(q1; kv2, text mask)"""
 
     @staticmethod
-    def forward(ctx, qkv1, qkv2, mask1, mask2, N, R, T, heads, p1, p2, rng, site1, site2):
-        _check(qkv1, "qkv1")
-        _check(qkv2, "qkv2")
-        assert qkv1.is_contiguous() and qkv2.is_contiguous()
-        Hb = qkv1.shape[1] // 3
+    def forward(ctx, q1, kv1, q2, kv2, mask1, mask2, N, R, T, heads, p1, p2, rng, site1, site2):
+        for t, nme in ((q1, "q1"), (kv1, "kv1"), (q2, "q2"), (kv2, "kv2")):
+            _check(t, nme)
+            assert t.is_contiguous() and t.dim() == 2
+        Hb = q1.shape[1]
         d = Hb // heads
         scale = 1.0 / math.sqrt(d)
-        L = 3 * Hb
-        ctx1 = torch.empty((N * T, Hb), dtype=torch.float32, device=qkv1.device)
-        ctx2 = torch.empty((N * R, Hb), dtype=torch.float32, device=qkv1.device)
-        lse1 = _attn_fwd(qkv2, 0, L, qkv1, Hb, L, qkv1, 2 * Hb, L, mask1, ctx1, N, heads, T, R, d, scale, p1, rng, site1)
-        lse2 = _attn_fwd(qkv1, 0, L, qkv2, Hb, L, qkv2, 2 * Hb, L, mask2, ctx2, N, heads, R, T, d, scale, p2, rng, site2)
+        ctx1 = torch.empty((N * T, Hb), dtype=torch.float32, device=q1.device)
+        ctx2 = torch.empty((N * R, Hb), dtype=torch.float32, device=q1.device)
+        lse1 = _attn_fwd(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, ctx1, N, heads, T, R, d, scale, p1, rng, site1)
+        lse2 = _attn_fwd(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, ctx2, N, heads, R, T, d, scale, p2, rng, site2)
         ctx.meta = (N, R, T, heads, Hb, d, scale, p1, p2, site1, site2)
-        ctx.save_for_backward(qkv1, qkv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng)
+        ctx.save_for_backward(q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng)
         ctx.mark_non_differentiable(lse1, lse2)
+        ctx.set_materialize_grads(False)
         return ctx1, ctx2, lse1, lse2
 
     @staticmethod
     def backward(ctx, d1, d2, _a, _b):
-        qkv1, qkv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng = ctx.saved_tensors
+        q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng = ctx.saved_tensors
         N, R, T, heads, Hb, d, scale, p1, p2, site1, site2 = ctx.meta
-        L = 3 * Hb
-        d1 = d1 if d1.is_contiguous() else d1.contiguous()
-        d2 = d2 if d2.is_contiguous() else d2.contiguous()
-        g1, g2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
-        # direction 1: q = query2 (text), k/v = key1/value1 (image)  -> dq2, dk1, dv1
-        _attn_bwd(qkv2, 0, L, qkv1, Hb, L, qkv1, 2 * Hb, L, mask1, ctx1, d1, lse1, g2, 0, L, g1, Hb, L, g1, 2 * Hb, L, N, heads, T, R,
-                  d, scale, p1, rng, site1)
-        # direction 2: q = query1 (image), k/v = key2/value2 (text)  -> dq1, dk2, dv2
-        _attn_bwd(qkv1, 0, L, qkv2, Hb, L, qkv2, 2 * Hb, L, mask2, ctx2, d2, lse2, g1, 0, L, g2, Hb, L, g2, 2 * Hb, L, N, heads, R, T,
-                  d, scale, p2, rng, site2)
-        return (g1, g2) + (None,) * 11
+        gq1 = gkv1 = gq2 = gkv2 = None
+        if d1 is not None:      # text queries over image keys/values -> dq2, dk1|dv1
+            d1 = d1 if d1.is_contiguous() else d1.contiguous()
+            gq2, gkv1 = torch.empty_like(q2), torch.empty_like(kv1)
+            _attn_bwd(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, ctx1, d1, lse1, gq2, 0, Hb, gkv1, 0, 2 * Hb, gkv1, Hb,
+                      2 * Hb, N, heads, T, R, d, scale, p1, rng, site1)
+        if d2 is not None:      # image queries over text keys/values -> dq1, dk2|dv2
+            d2 = d2 if d2.is_contiguous() else d2.contiguous()
+            gq1, gkv2 = torch.empty_like(q1), torch.empty_like(kv2)
+            _attn_bwd(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, ctx2, d2, lse2, gq1, 0, Hb, gkv2, 0, 2 * Hb, gkv2, Hb,
+                      2 * Hb, N, heads, R, T, d, scale, p2, rng, site2)
+        return (gq1, gkv1, gq2, gkv2) + (None,) * 11
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -504,6 +528,7 @@ class CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
+        ctx.set_materialize_grads(False)
         lg, M, V, ld = _rows2d(logits, "logits")
         tg = _i64(target, "target").reshape(-1)
         assert tg.numel() == M, (tg.shape, M)
@@ -518,6 +543,8 @@ class CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
         lg, tg, row_lse, out = ctx.saved_tensors
         M, V, ld, ign, shape = ctx.meta
         g = g.reshape(1).contiguous().float()
@@ -535,6 +562,7 @@ class KLMaskedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target, mask):
+        ctx.set_materialize_grads(False)
         pr, M, Cc, ld = _rows2d(pred, "pred")
         tg, M2, C2, ldt = _rows2d(target, "target")
         assert (M, Cc) == (M2, C2), (pred.shape, target.shape)
@@ -550,6 +578,8 @@ class KLMaskedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
         pr, tg, mk, row_lse, out = ctx.saved_tensors
         M, Cc, ld, ldt, shape = ctx.meta
         g = g.reshape(1).contiguous().float()
@@ -567,6 +597,7 @@ class BCEWithLogitsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, t, pos_weight):
+        ctx.set_materialize_grads(False)
         _check(x, "x")
         xc = x.contiguous()
         tc = t.to(torch.float32).contiguous()
@@ -578,6 +609,8 @@ class BCEWithLogitsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
         xc, tc, pw = ctx.saved_tensors
         g = g.reshape(1).contiguous().float()
         dx = torch.empty_like(xc)

@@ -13,7 +13,7 @@ the same numbers); all arithmetic goes through `ytvln.ops` -> libytvln.so:
   Bert(Image)SelfAttention.forward  :284-311 / :413-440  one packed QKV GEMM + fused flash attention (scores stay in registers)
   Bert(Image)SelfOutput / *Output   :321-325 / :364-368  GEMM + fused dropout+residual+LayerNorm kernel
   Bert(Image)Intermediate           :351-354             GEMM with erf-GELU epilogue (fused into ops.ffn with the next GEMM)
-  BertBiAttention.forward           :552-618             two packed QKV GEMMs + the same attention kernel in both directions
+  BertBiAttention.forward           :552-618             per-direction packed K|V GEMMs + the same attention kernel both ways
   heads                             :851-969             GEMM(+GELU) + LayerNorm kernel + decoder GEMM
 
 GPU only: tensors must be on a HIP device; there is no CPU path (use `oracle/` for CPU checks -- tests only).
@@ -376,20 +376,24 @@ class BertBiAttention(nn.Module):
         t = input_tensor2.shape[1]
         hb = self.all_head_size
         m1, m2 = _mask2d(attention_mask1, n, r), _mask2d(attention_mask2, n, t)
-        qkv1 = _PackedQKV.project(input_tensor1, self.query1, self.key1, self.value1).view(n * r, 3 * hb)
-        qkv2 = _PackedQKV.project(input_tensor2, self.query2, self.key2, self.value2).view(n * t, 3 * hb)
+        q1 = ops.linear(input_tensor1, self.query1.weight, self.query1.bias).view(n * r, hb)
+        kv1 = ops.linear(input_tensor1, torch.cat([self.key1.weight, self.value1.weight], 0),
+                         torch.cat([self.key1.bias, self.value1.bias], 0)).view(n * r, 2 * hb)
+        q2 = ops.linear(input_tensor2, self.query2.weight, self.query2.bias).view(n * t, hb)
+        kv2 = ops.linear(input_tensor2, torch.cat([self.key2.weight, self.value2.weight], 0),
+                         torch.cat([self.key2.bias, self.value2.bias], 0)).view(n * t, 2 * hb)
         p1, p2 = _p(self, self.dropout1.p), _p(self, self.dropout2.p)
-        st = _drop_state(self, qkv1) if (p1 > 0 or p2 > 0) else None
+        st = _drop_state(self, q1) if (p1 > 0 or p2 > 0) else None
         s1, s2 = (st.next_site(), st.next_site()) if st else (0, 0)
-        ctx1, ctx2, lse1, lse2 = ops.CoAttentionFn.apply(qkv1, qkv2, m1, m2, n, r, t, self.num_attention_heads, p1, p2,
+        ctx1, ctx2, lse1, lse2 = ops.CoAttentionFn.apply(q1, kv1, q2, kv2, m1, m2, n, r, t, self.num_attention_heads, p1, p2,
                                                          st.tensor if st else None, s1, s2)
         probs = (None, None)
         if self.want_probs:
             with torch.no_grad():
                 sc = 1.0 / math.sqrt(self.attention_head_size)
-                pr1 = ops.attn_probs(qkv2, 0, 3 * hb, qkv1, hb, 3 * hb, m1, lse1, n, self.num_attention_heads, t, r,
+                pr1 = ops.attn_probs(q2, 0, hb, kv1, 0, 2 * hb, m1, lse1, n, self.num_attention_heads, t, r,
                                      self.attention_head_size, sc)
-                pr2 = ops.attn_probs(qkv1, 0, 3 * hb, qkv2, hb, 3 * hb, m2, lse2, n, self.num_attention_heads, r, t,
+                pr2 = ops.attn_probs(q1, 0, hb, kv2, 0, 2 * hb, m2, lse2, n, self.num_attention_heads, r, t,
                                      self.attention_head_size, sc)
                 probs = (pr1, pr2)
         return ctx1.view(n, t, hb), ctx2.view(n, r, hb), probs
