@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Headline benchmark: ViLBERT pre-training throughput in traj-instr pairs/s on MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (N = 1 ... 8, weak scaling): BASELINE.json configs[1] per GPU -- full ViLBERT (12 text / 6 image / 6 co-attention
+layers, 250 M parameters), bs = 8 items x K = 7 options = 56 pairs, 80 tokens x (8 frames x 36 regions) x 2048-d, fp32,
+train mode (dropout on), one step = forward + MLM/MVM/ranking/traj losses + backward + (all-reduce) + fused AdamW + LR step,
+exactly the body of the reference's train_epoch (utils/utils_init.py:199-239).  Inputs are synthetic and resident in HBM.
+
+Prints ONE JSON line (rank 0).  Besides the driver contract it carries
+  roofline     -- the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their HIP-event time, measured
+                  live on the launch stream during the timed steps, against the 157.3 TFLOP/s fp32 matrix peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's path, oracle/vilbert_ref.py) timed on this box's host cores
+                  on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "youtube-vln_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+TRAIN_GFLOP_PER_PAIR = 223.9   # algorithmic, T=80 R=288 full config, training = 3 x forward (SURVEY.md 8d / BASELINE.md 3)
+
+WORKLOADS = {
+    # name: (config json, bs, K, T, frames, boxes, flags)
+    "cfg2_full_pretrain_bs8": ("bert_base_6_layer_6_connect.json", 8, 7, 80, 8, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
+    "cfg1_tiny_mlm_bs2": ("tiny_2_2_1.json", 2, 7, 16, 1, 8, dict(masked_language=True)),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2_full_pretrain_bs8", choices=sorted(WORKLOADS))
+    ap.add_argument("--bs", type=int, default=None, help="override items per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print per-shape GEMM timing to stderr")
+    ap.add_argument("--eval-dropout-off", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def make_args(flags):
+    a = dict(model_name="vilbert", ranking=False, traj_judge=False, masked_vision=False, masked_language=False, pretrain=True,
+             num_negatives=2, traj_loss_scale=1.0, not_traj_judge_data=False, local_rank=-1, skip_all_reduce=True,
+             weight_decay=0.01, learning_rate=4e-5, no_scheduler=False, ConstantLR=False, gradient_accumulation_steps=1,
+             num_epochs=1, warmup_proportion=0.2, cooldown_factor=2.0, resume=False)
+    a.update(flags)
+    return types.SimpleNamespace(**a)
+
+
+class GemmTimer:
+    """Brackets every GEMM launch with HIP events on the launch stream (torch's current stream = the stream the C ABI is
+    given) and sums algorithmic FLOPs; read out after the timed region."""
+
+    def __init__(self):
+        self.records = []
+        self.on = False
+
+    def install(self):
+        from ytvln import ops
+        inner = ops._gemm
+        timer = self
+
+        def timed(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw):
+            if not timer.on:
+                return inner(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
+            e1.record()
+            timer.records.append((e0, e1, M, N, K, int(transA), int(transB)))
+
+        ops._gemm = timed
+
+    def summary(self):
+        tot_ms, tot_flop, shapes = 0.0, 0.0, {}
+        for e0, e1, M, N, K, ta, tb in self.records:
+            ms = e0.elapsed_time(e1)
+            fl = 2.0 * M * N * K
+            tot_ms += ms
+            tot_flop += fl
+            s = shapes.setdefault((M, N, K, ta, tb), [0, 0.0, 0.0])
+            s[0] += 1; s[1] += ms; s[2] += fl
+        return tot_ms, tot_flop, len(self.records), shapes
+
+
+def effective_cores() -> int:
+    """Host cores this process may really use: min(affinity mask, cgroup CPU quota).  The GPU boxes expose 256 logical CPUs
+    behind a 16-CPU cgroup quota; sizing the thread pool by os.cpu_count() there throttles everything to a crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(workload, budget_s: float = 45.0):
+    """Oracle (port of the reference's PyTorch CPU path) on the host cores: bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vilbert_ref as O
+    from ytvln import synth
+    cfgname, _, K, T, frames, boxes, flags = WORKLOADS[workload]
+    cores = effective_cores()
+    torch.set_num_threads(cores)
+    cfgd = json.load(open(os.path.join(ROOT, "youtube-vln_amd", "configs", cfgname)))
+    ocfg = O.RefConfig(**cfgd)
+    oflags = O.TaskFlags(**flags)
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_schema.json")))["Lily/" + cfgname]["shapes"]
+    W = synth.make_weights({k: tuple(v) for k, v in shapes.items()}, seed=1)
+    S = {k: torch.from_numpy(v).clone() for k, v in W.items()}
+    bs = 1 if "full" in workload else 2
+    batch = synth.to_torch(synth.make_batch(bs=bs, K=K, T=T, frames=frames, boxes=boxes, seed=1234, ignore_rank_frac=0.0))
+    st = O.AdamWState()
+    times = []
+    begin = time.perf_counter()
+    for i in range(3):
+        t0 = time.perf_counter()
+        O.train_step(S, ocfg, oflags, batch, st, 4e-5, drop=True)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - begin + times[-1] > budget_s:      # bounded sample: never let the checker dominate the run
+            break
+    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"value": round(bs * K / med, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/vilbert_ref.py (port of the reference's PyTorch CPU path), {cfgname}, bs={bs} x K={K} = {bs * K} pairs, "
+                      f"T={T} R={frames * boxes}, fp32, dropout on, fwd + losses + bwd + AdamW; median of {max(1, len(times) - 1)} step(s) "
+                      f"after {1 if len(times) > 1 else 0} warm-up ({med:.2f} s/step)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.set_num_threads(effective_cores())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
+
+    from ytvln import synth, utils_init
+    from ytvln.distributed import DataParallel
+    from ytvln.lily import Lily
+    from ytvln.vilbert import BertConfig
+    from ytvln.vilbert_init import get_optimization
+
+    cfgname, bs, K, T, frames, boxes, flags = WORKLOADS[a.workload]
+    bs = a.bs or bs
+    args = make_args(flags)
+    args.local_rank = local_rank if world > 1 else -1
+    cfg = BertConfig.from_json_file(os.path.join(ROOT, "youtube-vln_amd", "configs", cfgname))
+    cfg.args = args
+    torch.manual_seed(1234)                      # identical initial weights on every rank (DDP would broadcast rank 0's)
+    model = Lily(cfg).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    model.train()
+    if a.eval_dropout_off:
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    batch = synth.to_torch(synth.make_batch(bs=bs, K=K, T=T, frames=frames, boxes=boxes, seed=1234 + rank), dev)
+    runner = model
+    if world > 1:
+        runner = DataParallel(model, broadcast=True)
+    opt, sched, _, _ = get_optimization(args, model, a.steps + a.warmup + 1, None)
+    if world > 1:
+        runner.attach(opt)
+
+    timer = GemmTimer()
+    if not a.no_kernel_timing:
+        timer.install()
+
+    def step(i):
+        return utils_init.train_step(runner, opt, sched, batch, args, i, all_options=True)
+
+    for i in range(a.warmup):
+        loss, _ = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss, _ = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+    assert np.isfinite(final_loss), "training diverged"
+
+    pairs_per_step = bs * K * world
+    value = pairs_per_step * a.steps / elapsed
+    out = {
+        "metric": "pretrain samples/sec (traj-instr pairs)", "value": round(value, 3), "unit": "pairs/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * elapsed / a.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": a.workload, "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
+                   "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
+                   "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
+                   "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}"},
+        "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
+    }
+    if "full" in a.workload and T == 80 and frames * boxes == 288:
+        out["model_tflops"] = round(value * TRAIN_GFLOP_PER_PAIR / 1000.0, 2)
+        out["model_mfma_frac"] = round(value / world * TRAIN_GFLOP_PER_PAIR / 1000.0 / PEAK_F32_MFMA_TFLOPS, 4)
+    if not a.no_kernel_timing and timer.records:
+        ms, flop, n, shapes = timer.summary()
+        ach = flop / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "ytvln::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 2),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": None, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
+                           "avg_launch_gflop": round(flop / n / 1e9, 3), "gemm_time_share": round(ms / (1000.0 * elapsed), 4)}
+        if a.kernel_table and rank == 0:
+            rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
+            print(f"{'M':>7} {'N':>6} {'K':>6} tA tB {'calls':>6} {'ms':>9} {'TF/s':>7}", file=sys.stderr)
+            for (M, N, Kk, ta, tb), (c, msx, fl) in rows[:40]:
+                print(f"{M:7d} {N:6d} {Kk:6d} {ta:2d} {tb:2d} {c:6d} {msx:9.3f} {fl / msx / 1e9:7.1f}", file=sys.stderr)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.workload)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
