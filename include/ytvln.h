@@ -46,10 +46,14 @@ enum {
  *   C[M,N] (+)= op(A)[M,K] . op(B)[K,N]
  *   transA = 0: A stored [M,K] (lda >= K)      transA = 1: A stored [K,M] (lda >= M)
  *   transB = 0: B stored [K,N] (ldb >= N)      transB = 1: B stored [N,K] (ldb >= K)   <- nn.Linear weight layout
- *   bias: [N] or NULL.  beta: 0 = overwrite, 1 = accumulate into C.  aux/ldaux: see the epilogue enum (may be NULL). */
+ *   bias: [N] or NULL.  beta: 0 = overwrite, 1 = accumulate into C.  aux/ldaux: see the epilogue enum (may be NULL).
+ *   workspace: optional scratch of ytvln_gemm_workspace_elems(M,N,K,epilogue) floats.  When it is supplied and the output
+ *   has too few 128x128 tiles to fill 256 CUs (weight gradients: [out,in] outputs contracted over N*T or N*R rows), the
+ *   contraction is split across workgroups and reduced in a fixed order (deterministic split-K); otherwise ignored. */
+int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
 int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
-                   float beta, void* stream);
+                   float beta, float* workspace, int64_t workspace_elems, void* stream);
 
 /* out[b, n] = sum over the b-th block of `rows_per_block` rows of x[:, n].  out is [ceil(M/rows_per_block), N] with
  * leading dimension ldo (bias gradients, position-embedding gradient, second stage of every column reduction). */

@@ -398,6 +398,24 @@ def g5(R):
     print("g5 ok")
 
 
+def g6(R):
+    """Seeded initialisation: torch.manual_seed(0); Lily(tiny) -> per-parameter checksums (the product builds its modules in
+    the reference's construction order, so the same seed must draw the same weights; vilbert.py:698-710, 991-1002, lily.py:56)."""
+    out = {}
+    for cfgname in ("micro.json", "tiny_2_2_1.json"):
+        rcfg, _ = load_cfg(R, cfgname)
+        rcfg.args = ref_args(ranking=True)
+        torch.manual_seed(0)
+        m = R.lily.Lily(rcfg)
+        sd = m.state_dict()
+        out[cfgname + "/names"] = np.array(list(sd))
+        out[cfgname + "/sum"] = np.array([v.double().sum().item() for v in sd.values()])
+        out[cfgname + "/norm"] = np.array([v.double().norm().item() for v in sd.values()])
+        out[cfgname + "/head"] = np.stack([np.pad(v.flatten()[:4].numpy(), (0, max(0, 4 - v.numel()))) for v in sd.values()])
+    np.savez_compressed(os.path.join(GOLD, "g6_seeded_init.npz"), **out)
+    print("g6 ok")
+
+
 def schema(R):
     """State-dict key -> shape for every config and both top-level model classes, plus weight-decay group membership
     as computed by the reference's own get_optimization (vilbert_init.py:9-18)."""
@@ -425,6 +443,6 @@ def schema(R):
 if __name__ == "__main__":
     R = ref_import.import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    todo = sys.argv[1:] or ["g5", "g0", "g1", "g3", "schema", "g2", "g4"]
+    todo = sys.argv[1:] or ["g5", "g0", "g1", "g3", "g6", "schema", "g2", "g4"]
     for name in todo:
         globals()[name](R)

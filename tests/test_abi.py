@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/ytvln.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_decls():
+    text = open(os.path.join(ROOT, "include", "ytvln.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(ytvln_\w+)\s*\(([^)]*)\)\s*;", text):
+        args = [a.strip() for a in m.group(3).split(",") if a.strip() and a.strip() != "void"]
+        decls[m.group(2)] = (m.group(1), args)
+    return decls
+
+
+def ctype_of(arg):
+    if "*" in arg:
+        return ctypes.c_void_p
+    if arg.startswith("int64_t"):
+        return ctypes.c_int64
+    if arg.startswith("int "):
+        return ctypes.c_int
+    if arg.startswith("float "):
+        return ctypes.c_float
+    raise AssertionError(arg)
+
+
+def test_build_entry_point_compiles_and_loads():
+    import __graft_entry__ as g
+    g.build()
+    from ytvln import _lib
+    lib = _lib.load()
+    assert lib.ytvln_version() == _lib.ABI_VERSION == 1
+    assert lib.ytvln_last_error() is not None
+
+
+def test_every_declared_symbol_is_exported_and_bound_with_the_declared_signature():
+    from ytvln import _lib
+    lib = _lib.load()
+    decls = header_decls()
+    assert len(decls) >= 24
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in exported.splitlines() if " T " in l}
+    for name, (ret, args) in decls.items():
+        assert name in exported, f"{name} declared in ytvln.h but not exported"
+        assert hasattr(lib, name)
+        if name in ("ytvln_version", "ytvln_last_error"):
+            continue
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+        want = [ctype_of(a) for a in args]
+        assert _lib.SIGNATURES[name] == want, f"{name}: ctypes table {_lib.SIGNATURES[name]} != header {want}"
+    assert set(_lib.SIGNATURES) <= set(decls), set(_lib.SIGNATURES) - set(decls)
+    assert {e for e in exported if e.startswith("ytvln_")} == set(decls), "exported symbols and header disagree"
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    from ytvln import _lib
+    lib = _lib.load()
+    rc = lib.ytvln_gemm_f32(None, 1, 0, None, 1, 0, None, 1, None, None, 0, 4, 4, 4, 0, 0.0, None, 0, None)
+    assert rc != 0 and b"null" in lib.ytvln_last_error()
+    with pytest.raises(RuntimeError, match="ytvln_ln_fwd_f32 failed"):
+        _lib.call("ytvln_ln_fwd_f32", 16, None, 16, 16, 16, None, None, None, 4, 30, 1e-12, 0.0, 0.0, None, 0, None)   # H % 4 != 0
+    assert lib.ytvln_gemm_workspace_elems(1024, 1024, 16128, 0) > 0
+    assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) == 0
+    assert lib.ytvln_ln_bwd_blocks(16128) == 1008
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ytvln import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.YtvlnLibraryError, match="no CPU / PyTorch fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected_no_silent_fallback():
+    import torch
+    from ytvln import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8), None)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.cross_entropy(torch.zeros(4, 8), torch.zeros(4, dtype=torch.long), -1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "youtube-vln_amd", "ytvln")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "vilbert_ref" not in src and "import oracle" not in src and "from oracle" not in src, f

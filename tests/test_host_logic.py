@@ -1,0 +1,140 @@
+"""CPU: host-side logic of the product (no kernels run): state-dict schema, seeded init, grouping, schedules, synth data."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from helpers import args_ns, cfg_dict, gold
+
+
+def make_lily(cfgname, **flags):
+    from ytvln.lily import Lily
+    from ytvln.vilbert import BertConfig
+    cfg = BertConfig(**cfg_dict(cfgname))
+    cfg.args = args_ns(**(flags or dict(ranking=True)))
+    return Lily(cfg)
+
+
+@pytest.mark.parametrize("cfgname", ["micro.json", "tiny_2_2_1.json"])
+def test_state_dict_schema_matches_reference(cfgname):
+    schema = json.load(open(os.path.join(GOLD, "state_dict_schema.json")))
+    ref = schema["Lily/" + cfgname]
+    m = make_lily(cfgname)
+    sd = m.state_dict()
+    assert list(sd) == list(ref["shapes"]) or set(sd) == set(ref["shapes"])
+    for k, v in sd.items():
+        assert list(v.shape) == ref["shapes"][k], k
+    assert [n for n, _ in m.named_parameters()] == ref["param_order"]
+    assert sum(p.numel() for p in m.parameters()) == ref["n_params"]
+    assert sd["cls.predictions.decoder.weight"].data_ptr() == sd["bert.embeddings.word_embeddings.weight"].data_ptr()
+    from ytvln.vilbert import BertForMultiModalPreTraining, BertConfig
+    mm = BertForMultiModalPreTraining(BertConfig(**cfg_dict(cfgname)))
+    r2 = schema["BertForMultiModalPreTraining/" + cfgname]
+    assert [n for n, _ in mm.named_parameters()] == r2["param_order"]
+    assert {k: list(v.shape) for k, v in mm.state_dict().items()} == r2["shapes"]
+
+
+def test_full_config_parameter_count_and_decay_groups():
+    schema = json.load(open(os.path.join(GOLD, "state_dict_schema.json")))
+    ref = schema["Lily/bert_base_6_layer_6_connect.json"]
+    from ytvln.vilbert_init import NO_DECAY
+    no_decay = [n for n in ref["param_order"] if any(nd in n for nd in NO_DECAY)]
+    assert no_decay == ref["no_decay"]          # as grouped by the reference's own get_optimization
+    assert "bert.encoder.c_layer.0.biOutput.LayerNorm1.weight" not in no_decay      # the substring quirk
+    assert ref["n_params"] == 250087039
+
+
+@pytest.mark.parametrize("cfgname", ["micro.json", "tiny_2_2_1.json"])
+def test_seeded_initialisation_draws_the_reference_numbers(cfgname):
+    g = gold("g6_seeded_init.npz")
+    torch.manual_seed(0)
+    m = make_lily(cfgname)
+    sd = m.state_dict()
+    assert list(sd) == g[cfgname + "/names"].tolist()
+    for i, (k, v) in enumerate(sd.items()):
+        assert abs(float(v.double().sum()) - g[cfgname + "/sum"][i]) <= 1e-9 * max(1.0, abs(g[cfgname + "/sum"][i])), k
+        assert abs(float(v.double().norm()) - g[cfgname + "/norm"][i]) <= 1e-9 * max(1.0, g[cfgname + "/norm"][i]), k
+        assert np.array_equal(np.pad(v.flatten()[:4].numpy(), (0, max(0, 4 - v.numel()))), g[cfgname + "/head"][i]), k
+
+
+def test_config_is_strict_and_round_trips(tmp_path):
+    from ytvln.vilbert import BertConfig
+    with pytest.raises(TypeError):
+        BertConfig(not_a_field=1)
+    with pytest.raises(AssertionError):
+        BertConfig(v_biattention_id=(0, 5), t_biattention_id=(1, 2))
+    c = BertConfig(**cfg_dict("tiny_2_2_1.json"))
+    p = tmp_path / "c.json"
+    p.write_text(c.to_json_string())
+    assert BertConfig.from_json_file(p).to_dict() == c.to_dict()
+
+
+def test_schedules_and_get_optimization():
+    from ytvln.optimization import AdamW, ConstantLRSchedule, WarmupLinearSchedule
+    from ytvln.vilbert_init import get_optimization
+    k = gold("g5_kats.npz")
+    warm, tot = k["sched/warm_total"]
+    p = torch.nn.Parameter(torch.zeros(3))
+    sch = WarmupLinearSchedule(torch.optim.SGD([p], lr=1.0), warm, tot)
+    for s, lam in zip(k["sched/steps"], k["sched/lambda"]):
+        assert abs(sch.lr_lambda(int(s)) - lam) < 1e-15
+    m = make_lily("micro.json")
+    opt, sched, _, start = get_optimization(args_ns(), m, 10, None)
+    assert isinstance(opt, AdamW) and isinstance(sched, WarmupLinearSchedule) and start == 0
+    assert (sched.warmup_steps, sched.t_total) == (2.0, 18.0)
+    assert [g["weight_decay"] for g in opt.param_groups] == [0.0, 0.01]
+    assert opt.defaults["eps"] == 1e-6 and opt.defaults["betas"] == (0.9, 0.999)
+    _, sched2, _, _ = get_optimization(args_ns(no_scheduler=True), m, 10, None)
+    assert isinstance(sched2, ConstantLRSchedule)
+    with pytest.raises(ValueError):
+        AdamW([p], lr=-1)
+    with pytest.raises(ValueError):
+        AdamW([p], betas=(1.0, 0.9))
+
+
+def test_synthetic_batch_layout_and_determinism():
+    from ytvln import synth
+    a = synth.make_batch(bs=2, K=7, T=16, frames=2, boxes=4, seed=5)
+    b = synth.make_batch(bs=2, K=7, T=16, frames=2, boxes=4, seed=5)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert len(a) == 16
+    assert a[1].shape == (2, 7, 8, 2048) and a[1].dtype == np.float32 and a[2].shape == (2, 7, 8, 12)
+    assert a[4].shape == (2, 7, 8, 1601) and a[6].dtype == np.int64 and a[7].dtype == np.bool_ and a[13].dtype == np.bool_
+    assert np.array_equal(a[7], a[6] > 0)
+    assert set(np.unique(a[2][..., 11]).tolist()) <= {0.0, 1.0}
+    assert np.all((a[8] == -1) | (a[8] > 0))
+    np.testing.assert_allclose(a[4].sum(-1), 1.0, rtol=1e-4)
+    c = synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, opt_holes=1, ignore_rank_frac=0.0)
+    assert c[13].sum() == 5
+    w1 = synth.make_weights({"a.weight": (3, 4), "x.LayerNorm.weight": (4,), "a.bias": (3,)}, 1)
+    w2 = synth.make_weights({"x.LayerNorm.weight": (4,), "a.bias": (3,), "a.weight": (3, 4)}, 1)
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+
+
+def test_get_model_input_and_pad_packed_on_host():
+    from ytvln import synth
+    from ytvln import utils_init as U
+    k = gold("g5_kats.npz")
+    out = U.pad_packed(torch.from_numpy(k["pad_packed/t"]), torch.from_numpy(k["pad_packed/mask"]))
+    assert np.array_equal(out.numpy(), k["pad_packed/out"])
+    nb = synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, opt_holes=1, ignore_rank_frac=0.0)
+    batch = synth.to_torch(nb)
+    inp = U.get_model_input(batch)
+    assert inp[0].shape == (5, 8) and inp[1].shape == (5, 6, 16) and inp[2].shape == (5, 6, 12) and inp[5].shape == (5, 6)
+    nb2 = synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21)
+    b2 = synth.to_torch(nb2)
+    fast, slow = U.get_model_input(b2, all_options=True), U.get_model_input(b2, all_options=False)
+    assert all(torch.equal(x, y) for x, y in zip(fast[:6], slow[:6]))
+
+
+def test_model_refuses_cpu_inputs():
+    from ytvln import synth
+    from ytvln import utils_init as U
+    m = make_lily("micro.json")
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(*U.get_model_input(batch))

@@ -10,6 +10,7 @@
 // (row pitch BM+1 -> conflict-free); operands with M/N contiguous (dY^T, x^T views for the backward GEMMs) are written
 // with 16-byte stores (row pitch BM).
 #include "common.h"
+#include <algorithm>
 
 namespace ytvln {
 
@@ -23,6 +24,8 @@ struct GemmArgs {
     float beta;
     int vecA, vecB;   // 16-byte aligned vector loads legal for the operand
     int tiles_n, ntiles;
+    int splits, kchunk;   // split-K: blockIdx.y owns k in [y*kchunk, (y+1)*kchunk); partial tiles go to ws[y][M][N]
+    float* ws;
 };
 
 constexpr int BK = 32;
@@ -115,9 +118,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[LA::NV], rb[LB::NV];
-    const int nk = (g.K + BK - 1) / BK;
-    LA::load(ra, g.A, g.lda, g.M, g.K, m0, 0, g.vecA, tid);
-    LB::load(rb, g.B, g.ldb, g.N, g.K, n0, 0, g.vecB, tid);
+    const int kbeg = blockIdx.y * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);          // loaders zero-fill past kend
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
+    LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg, g.vecB, tid);
     LA::store(ra, As, tid);
     LB::store(rb, Bs, tid);
     __syncthreads();
@@ -125,8 +130,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            LA::load(ra, g.A, g.lda, g.M, g.K, m0, (kt + 1) * BK, g.vecA, tid);
-            LB::load(rb, g.B, g.ldb, g.N, g.K, n0, (kt + 1) * BK, g.vecB, tid);
+            LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg + (kt + 1) * BK, g.vecA, tid);
+            LB::load(rb, g.B, g.ldb, g.N, kend, n0, kbeg + (kt + 1) * BK, g.vecB, tid);
         }
         const float* a_s = As + cur * SA + half * LA::LD + wm0 + l31;
         const float* b_s = Bs + cur * SB + half * LB::LD + wn0 + l31;
@@ -151,6 +156,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 
     // epilogue: lane owns column l31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*half
+    if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
+        float* w = g.ws + (int64_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn0 + 32 * j + l31;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < g.M) w[(int64_t)row * g.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn0 + 32 * j + l31;
@@ -181,11 +202,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
+// C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
+                                                            const float* __restrict__ bias, int M, int N, int splits, float beta) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / N), col = (int)(i % N);
+        float acc = ws[i];
+        for (int s = 1; s < splits; ++s) acc += ws[(int64_t)s * total + i];
+        if (bias) acc += bias[col];
+        float* cp = C + (int64_t)row * ldc + col;
+        if (beta != 0.f) acc += beta * *cp;
+        *cp = acc;
+    }
+}
+
+// split-K plan: only for plain (no activation) GEMMs whose 128x128 tiling cannot fill the chip
+static int plan_splits(int M, int N, int K, int epilogue) {
+    if (epilogue != YTVLN_EPI_NONE) return 1;
+    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
+    if (tiles >= 384 || K < 1024) return 1;
+    int splits = (int)std::min<int64_t>(cdiv(640, tiles), K / 256);
+    return std::max(1, std::min(splits, 64));
+}
+
 template <int BM, int BN>
 static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.tiles_n = (int)cdiv(g.N, BN);
     g.ntiles = (int)cdiv(g.M, BM) * g.tiles_n;
-    dim3 grid(g.ntiles), block(256);
+    dim3 grid(g.ntiles, g.splits), block(256);
     if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
     else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
     else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
@@ -197,9 +242,14 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
 
 using namespace ytvln;
 
+extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
+    const int splits = plan_splits(M, N, K, epilogue);
+    return splits > 1 ? (int64_t)splits * M * N : 0;
+}
+
 extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                               int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
-                              int epilogue, float beta, void* stream) {
+                              int epilogue, float beta, float* workspace, int64_t workspace_elems, void* stream) {
     YT_REQUIRE(A && B && C, "gemm: null operand");
     YT_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
     YT_REQUIRE(epilogue >= YTVLN_EPI_NONE && epilogue <= YTVLN_EPI_MUL_DRELU, "gemm: bad epilogue %d", epilogue);
@@ -213,11 +263,26 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     hipStream_t s = as_stream(stream);
-    // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (256 CUs, 2 resident 128x128 blocks/CU)
-    const int64_t b128 = cdiv(M, 128) * cdiv(N, 128), b12864 = cdiv(M, 128) * cdiv(N, 64);
-    if (b128 >= 384) launch_tile<128, 128>(g, transA, transB, s);
-    else if (b12864 >= 384) launch_tile<128, 64>(g, transA, transB, s);
-    else launch_tile<64, 64>(g, transA, transB, s);
+    g.splits = 1; g.kchunk = K; g.ws = nullptr;
+    const int want = plan_splits(M, N, K, epilogue);
+    if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
+        g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
+        g.splits = (int)cdiv(K, g.kchunk);
+        g.ws = workspace;
+    }
+    if (g.splits > 1) {
+        launch_tile<128, 128>(g, transA, transB, s);
+        const int64_t total = (int64_t)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, s, workspace, C,
+                           ldc, bias, M, N, g.splits, beta);
+    } else {
+        g.splits = 1;
+        // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (256 CUs, 2 resident 128x128 blocks/CU)
+        const int64_t b128 = cdiv(M, 128) * cdiv(N, 128), b12864 = cdiv(M, 128) * cdiv(N, 64);
+        if (b128 >= 384) launch_tile<128, 128>(g, transA, transB, s);
+        else if (b12864 >= 384) launch_tile<128, 64>(g, transA, transB, s);
+        else launch_tile<64, 64>(g, transA, transB, s);
+    }
     YT_LAUNCH_CHECK("gemm_f32");
     return 0;
 }

@@ -23,7 +23,8 @@ P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
 # name -> argtypes, exactly mirroring include/ytvln.h (tests/test_abi.py checks header <-> table <-> exported symbols)
 SIGNATURES = {
-    "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P],
+    "ytvln_gemm_workspace_elems": [I32, I32, I32, I32],
+    "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, P],
     "ytvln_colsum_f32": [P, I64, I32, I32, P, I64, I32, P],
     "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
     "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],
@@ -76,7 +77,7 @@ def load():
         except AttributeError as e:
             raise YtvlnLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = I32
+        fn.restype = I64 if name == "ytvln_gemm_workspace_elems" else I32
     if lib.ytvln_version() != ABI_VERSION:
         raise YtvlnLibraryError(f"ABI mismatch: library {lib.ytvln_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -88,9 +88,17 @@ class DropoutState:
 # ------------------------------------------------------------------------------------------------------------------
 # GEMM primitives
 # ------------------------------------------------------------------------------------------------------------------
+_WS_CACHE = {}
+
+
 def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0):
+    key = (M, N, K, epi)
+    need = _WS_CACHE.get(key)
+    if need is None:
+        need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, K, epi))
+    ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
     call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
-         M, N, K, epi, float(beta), _stream())
+         M, N, K, epi, float(beta), _ptr(ws), need, _stream())
 
 
 def colsum(x: Tensor, M: int, N: int, ld: int) -> Tensor:
