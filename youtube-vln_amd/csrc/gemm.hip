@@ -11,6 +11,7 @@
 // with 16-byte stores (row pitch BM).
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace ytvln {
 
@@ -26,6 +27,7 @@ struct GemmArgs {
     int tiles_n, ntiles;
     int splits, kchunk;   // split-K: blockIdx.y owns k in [y*kchunk, (y+1)*kchunk); partial tiles go to ws[y][M][N]
     float* ws;
+    int fast;             // LDS-DMA main loop legal (K % 32 == 0, aligned operands, M/N-contiguous extents % 4 == 0)
 };
 
 constexpr int BK = 32;
@@ -92,6 +94,55 @@ struct TileLoader {
     }
 };
 
+// Epilogue shared by both main loops: lane owns column l31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*half.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half) {
+    if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
+        float* w = g.ws + (int64_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + 32 * j + l31;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < g.M) w[(int64_t)row * g.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + 32 * j + l31;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                float* cp = g.C + (int64_t)row * g.ldc + col;
+                switch (g.epilogue) {
+                    case YTVLN_EPI_GELU:
+                        if (g.aux) g.aux[(int64_t)row * g.ldaux + col] = v;
+                        v = gelu_erf(v);
+                        break;
+                    case YTVLN_EPI_RELU: v = fmaxf(v, 0.f); break;
+                    case YTVLN_EPI_MUL_DGELU: v *= dgelu_erf(g.aux[(int64_t)row * g.ldaux + col]); break;
+                    case YTVLN_EPI_MUL_DRELU: v = g.aux[(int64_t)row * g.ldaux + col] > 0.f ? v : 0.f; break;
+                    default: break;
+                }
+                if (g.beta != 0.f) v += g.beta * *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     using LA = TileLoader<BM, A_KC>;
@@ -155,51 +206,128 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: lane owns column l31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*half
-    if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
-        float* w = g.ws + (int64_t)blockIdx.y * g.M * g.N;
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path: tiles fed by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through VGPRs, no ds_write),
+// branch-free addressing (out-of-range rows / columns are CLAMPED to valid ones; their products land in accumulator
+// rows / columns the epilogue never stores), one barrier per k-tile with the next tile's DMA in flight under the MFMAs.
+// LDS images (the DMA writes lane-linear 1 KiB pieces, so the layout is chosen through the per-lane SOURCE address):
+//   K-contiguous operand  : S[m][32]   16-byte granule g of row m stored at position g ^ (m & 7)  -> ds_read_b128 of
+//                           4 consecutive k for a fixed m is (at most 2-way) conflict-free;
+//   M/N-contiguous operand: S[k][BMN]  k-major                                           -> conflict-free ds_read_b32.
+// The contraction of one 32-deep tile is split between half-waves (half h owns k in [16h, 16h+16)), so a lane feeds four
+// consecutive MFMAs from one 16-byte LDS read.  Requires K % 32 == 0 and 16-byte aligned operands (else: generic kernel).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int BMN, bool KC>
+struct DmaTile {
+    static constexpr int NI = BMN / 32;            // 1 KiB pieces per wave per tile (4 waves)
+    // per-lane source pointer of piece i for the tile starting at k0 (advanced by the caller)
+    __device__ static __forceinline__ const float* src(const float* P, int64_t ld, int MN, int mn0, int k0, int wave, int lane, int i) {
+        const int c = wave * NI + i;
+        if (KC) {
+            const int m = c * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ ((lane >> 3) & 7);
+            const int row = min(mn0 + m, MN - 1);
+            return P + (int64_t)row * ld + k0 + 4 * g;
+        } else {
+            const int per_row = BMN / 4;                       // float4 per k-row
+            const int k = (c * 64 + lane) / per_row, mn = ((c * 64 + lane) % per_row) * 4;
+            const int col = min(mn0 + mn, MN - 4);
+            return P + (int64_t)(k0 + k) * ld + col;
+        }
+    }
+    __device__ static __forceinline__ int64_t step(int64_t ld) { return KC ? 32 : 32 * ld; }   // floats per k-tile
+    // operand values for k-group sg (k = 16*half + 4*sg + 0..3) of the wave sub-tile starting at row/col w0 + 32*i
+    __device__ static __forceinline__ float4 frag(const float* S, int w0, int i, int l31, int half, int sg) {
+        if (KC) {
+            const int row = w0 + 32 * i + l31;
+            return *reinterpret_cast<const float4*>(S + row * 32 + 4 * ((half * 4 + sg) ^ (row & 7)));
+        } else {
+            const float* p = S + (16 * half + 4 * sg) * BMN + w0 + 32 * i + l31;
+            return make_float4(p[0], p[BMN], p[2 * BMN], p[3 * BMN]);
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
+    using TA = DmaTile<BM, A_KC>;
+    using TB = DmaTile<BN, B_KC>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int SA = BM * 32, SB = BN * 32, STAGE = SA + SB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];     // ONE shared object (see guide: DMA + 2nd object de-pipelines)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int t = xcd_remap(blockIdx.x, g.ntiles);
+    const int m0 = (t / g.tiles_n) * BM, n0 = (t % g.tiles_n) * BN;
+    const int kbeg = blockIdx.y * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg) / BK;
+
+    const float* pa[TA::NI];
+    const float* pb[TB::NI];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn0 + 32 * j + l31;
-            if (col >= g.N) continue;
+    for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.M, m0, kbeg, wave, lane, i);
+#pragma unroll
+    for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.N, n0, kbeg, wave, lane, i);
+    const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int stage) {
+        float* As = smem + stage * STAGE;
+        float* Bs = As + SA;
+#pragma unroll
+        for (int i = 0; i < TA::NI; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
+            pa[i] += sa;
+        }
+#pragma unroll
+        for (int i = 0; i < TB::NI; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
+            pb[i] += sb;
+        }
+    };
+
+    if (nk > 0) issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // my pieces of tile kt have landed; after the barrier everybody's have, and everybody is done reading the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue((kt + 1) & 1);
+        const float* As = smem + (kt & 1) * STAGE;
+        const float* Bs = As + SA;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < g.M) w[(int64_t)row * g.N + col] = acc[i][j][r];
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        return;
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn0 + 32 * j + l31;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                float* cp = g.C + (int64_t)row * g.ldc + col;
-                switch (g.epilogue) {
-                    case YTVLN_EPI_GELU:
-                        if (g.aux) g.aux[(int64_t)row * g.ldaux + col] = v;
-                        v = gelu_erf(v);
-                        break;
-                    case YTVLN_EPI_RELU: v = fmaxf(v, 0.f); break;
-                    case YTVLN_EPI_MUL_DGELU: v *= dgelu_erf(g.aux[(int64_t)row * g.ldaux + col]); break;
-                    case YTVLN_EPI_MUL_DRELU: v = g.aux[(int64_t)row * g.ldaux + col] > 0.f ? v : 0.f; break;
-                    default: break;
-                }
-                if (g.beta != 0.f) v += g.beta * *cp;
-                *cp = v;
-            }
-        }
-    }
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half);
 }
 
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic
@@ -231,6 +359,13 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.tiles_n = (int)cdiv(g.N, BN);
     g.ntiles = (int)cdiv(g.M, BM) * g.tiles_n;
     dim3 grid(g.ntiles, g.splits), block(256);
+    if (g.fast) {
+        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true>), grid, block, 0, s, g);
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false>), grid, block, 0, s, g);
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true>), grid, block, 0, s, g);
+        return 0;
+    }
     if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
     else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
     else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
@@ -264,6 +399,8 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     hipStream_t s = as_stream(stream);
     g.splits = 1; g.kchunk = K; g.ws = nullptr;
+    g.fast = (K > 0) && (K % BK == 0) && g.vecA && g.vecB && (transA ? (M % 4 == 0 && M >= 4) : true) &&
+             (!transB ? (N % 4 == 0 && N >= 4) : true) && !getenv("YTVLN_GEMM_GENERIC");
     const int want = plan_splits(M, N, K, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
