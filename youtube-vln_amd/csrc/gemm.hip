@@ -222,9 +222,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int BMN, bool KC>
+template <int BMN, bool KC, int NW>
 struct DmaTile {
-    static constexpr int NI = BMN / 32;            // 1 KiB pieces per wave per tile (4 waves)
+    static constexpr int NI = BMN / 8 / NW;        // 1 KiB pieces per wave per tile (BMN/8 pieces, NW waves)
     // per-lane source pointer of piece i for the tile starting at k0 (advanced by the caller)
     __device__ static __forceinline__ const float* src(const float* P, int64_t ld, int MN, int mn0, int k0, int wave, int lane, int i) {
         const int c = wave * NI + i;
@@ -253,17 +253,18 @@ struct DmaTile {
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
-    using TA = DmaTile<BM, A_KC>;
-    using TB = DmaTile<BN, B_KC>;
-    constexpr int TM = BM / 64, TN = BN / 64;
+template <int BM, int BN, bool A_KC, bool B_KC, int VAR, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
+    using TA = DmaTile<BM, A_KC, NW>;
+    using TB = DmaTile<BN, B_KC, NW>;
+    constexpr int WM = NW / 2;                         // waves along m (x 2 along n)
+    constexpr int TM = BM / WM / 32, TN = BN / 64;
     constexpr int SA = BM * 32, SB = BN * 32, STAGE = SA + SB;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];     // ONE shared object (see guide: DMA + 2nd object de-pipelines)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave >> 1) * (BM / WM), wn0 = (wave & 1) * (BN / 2);
     const int t = xcd_remap(blockIdx.x, g.ntiles);
     const int m0 = (t / g.tiles_n) * BM, n0 = (t % g.tiles_n) * BN;
     const int kbeg = blockIdx.y * g.kchunk;
@@ -300,22 +301,20 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
             pb[i] += sb;
         }
     };
-
-    if (nk > 0) issue(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // my pieces of tile kt have landed; after the barrier everybody's have, and everybody is done reading the other stage
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue((kt + 1) & 1);
-        const float* As = smem + (kt & 1) * STAGE;
-        const float* Bs = As + SA;
+    auto mma = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
+        if (VAR & 2) __builtin_amdgcn_s_setprio(1);
+        if (VAR & 4) {      // k-major order: consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            float4 a[TM], b[TN];
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = c == 0 ? a[i].x : c == 1 ? a[i].y : c == 2 ? a[i].z : a[i].w;
+                        const float bv = c == 0 ? b[j].x : c == 1 ? b[j].y : c == 2 ? b[j].z : b[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -325,6 +324,50 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
+        }
+        if (VAR & 2) __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (nk > 0) issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // my pieces of tile kt have landed; after the barrier everybody's have, and everybody is done reading the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue((kt + 1) & 1);
+        const float* As = smem + (kt & 1) * STAGE;
+        const float* Bs = As + SA;
+        if (VAR & 1) {      // fragments of k-group sg+1 are fetched while the MFMAs of group sg run
+            float4 a0[TM], b0[TN], a1[TM], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = TA::frag(As, wm0, i, l31, half, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[j] = TB::frag(Bs, wn0, j, l31, half, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = TA::frag(As, wm0, i, l31, half, 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = TB::frag(Bs, wn0, j, l31, half, 1);
+            mma(a0, b0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = TA::frag(As, wm0, i, l31, half, 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[j] = TB::frag(Bs, wn0, j, l31, half, 2);
+            mma(a1, b1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = TA::frag(As, wm0, i, l31, half, 3);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = TB::frag(Bs, wn0, j, l31, half, 3);
+            mma(a0, b0);
+            mma(a1, b1);
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                float4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
+                mma(a, b);
+            }
         }
     }
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half);
@@ -360,10 +403,28 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.ntiles = (int)cdiv(g.M, BM) * g.tiles_n;
     dim3 grid(g.ntiles, g.splits), block(256);
     if (g.fast) {
-        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true>), grid, block, 0, s, g);
-        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false>), grid, block, 0, s, g);
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true>), grid, block, 0, s, g);
+#define YT_DMA(V, NW)                                                                                                                   \
+    do {                                                                                                                               \
+        dim3 blk(NW * 64);                                                                                                             \
+        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, V, NW>), grid, blk, 0, s, g);                    \
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, V, NW>), grid, blk, 0, s, g);             \
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, V, NW>), grid, blk, 0, s, g);             \
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, V, NW>), grid, blk, 0, s, g);                                     \
+    } while (0)
+        const char* ev = getenv("YTVLN_GEMM_VARIANT");
+        const int var = ev ? atoi(ev) : 0;
+        // 128x128 tiles run 8 waves per workgroup (4 per SIMD at 2 workgroups/CU): measured 113 -> 121 TFLOP/s on
+        // 16128x1024x1024 and 84 -> 105 on the split-K weight gradients versus 4 waves (barrier coupling across SIMDs).
+        if constexpr (BM == 128 && BN == 128) {
+            if (var == 4) YT_DMA(0, 4);
+            else YT_DMA(0, 8);
+        } else if constexpr (BM == 128) {
+            if (var == 8) YT_DMA(0, 8);
+            else YT_DMA(0, 4);
+        } else {
+            YT_DMA(0, 4);
+        }
+#undef YT_DMA
         return 0;
     }
     if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
