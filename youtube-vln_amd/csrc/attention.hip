@@ -13,9 +13,9 @@
 //     because "reg r of lane l" is exactly the (k = key, column = query) element the MFMA wants when the contraction
 //     index is visited in the permuted order key(r, half) = (r&3) + 8*(r>>2) + 4*half  (a sum is order-free);
 //   * the contraction over the head dimension is split between half-waves (half 0: dk in [0, DP/2), half 1: the rest) so
-//     each lane fetches its K operand with ds_read_b128 from a row padded by 4 floats (conflict-free, section LDS of the guide);
+//     each lane fetches its K operand with ds_read_b128 from an XOR-swizzled row (<= 2-way conflict, section LDS of the guide);
 //   * O^T keeps the query on the lane, so the online-softmax rescale and the final 1/l are per-lane scalars.
-// K/V tiles of 32 keys are staged in LDS once per workgroup (NW waves = 32*NW queries share them).
+// K/V tiles of 32 keys are streamed through a two-stage LDS ring by LDS-DMA, shared by the NW waves (32*NW queries) of a workgroup.
 //
 // Backward = recompute-based flash backward split in two kernels with the same fragment tricks:
 //   dq kernel  (workgroup owns queries, loops over key tiles):  S^T, dP^T = V . dO^T, dS^T -> dQ^T += K^T . dS^T
@@ -39,6 +39,7 @@ struct AttnArgs {
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define RESCALE_THR 12.0f    // e^12 ~ 1.6e5: far inside fp32 range even summed over thousands of keys
 
 __device__ __forceinline__ int krow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -46,21 +47,54 @@ __device__ __forceinline__ int krow(int r, int half) { return (r & 3) + 8 * (r >
 // additive mask is -10000, so an fma here would change fully-masked rows at the 1e-3 level.
 __device__ __forceinline__ float score(float s, float scale, float mask) { return __fadd_rn(__fmul_rn(s, scale), mask); }
 
-// cooperative global -> LDS copy of a 32-row tile of head `h` (rows row0.., zero-filled past nrows / past d)
-template <int DP, int LD>
-__device__ __forceinline__ void stage_tile(float* __restrict__ S, const float* __restrict__ base, int64_t ld, int64_t row_base,
-                                           int row0, int nrows, int col0, int d, int tid, int nthr) {
-    constexpr int C4 = DP / 4;
-    for (int idx = tid; idx < 32 * C4; idx += nthr) {
-        const int row = idx / C4, c4 = idx % C4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + row < nrows && c4 * 4 < d)
-            v = *reinterpret_cast<const float4*>(base + (row_base + row0 + row) * ld + col0 + c4 * 4);
-        *reinterpret_cast<float4*>(S + row * LD + c4 * 4) = v;
+// ---- LDS tile streaming ------------------------------------------------------------------------------------------------
+// A 32 x DP tile lives in LDS as S[row][DP] with the 16-byte granule g of row r stored at position g ^ (r & 7).  Tiles are
+// fed by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a two-stage ring, so the next tile is in
+// flight under the current tile's MFMAs; the DMA writes lane-linear 1 KiB pieces, so the swizzle is applied to the per-lane
+// SOURCE address.  Rows past the end / columns past d are CLAMPED to valid data (finite garbage): such keys carry a -inf
+// mask (p = 0), such queries a +inf lse (p = 0), and garbage columns only reach accumulator columns that are never stored.
+// Reads: 4 consecutive dk of one row = one ds_read_b128 (<= 2-way conflict); 32 consecutive columns of one row = ds_read_b32.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int DP>
+struct Tile {
+    static constexpr int PIECES = DP / 8;    // 1 KiB pieces per 32-row tile
+    __device__ static __forceinline__ void issue(float* S, const float* __restrict__ base, int64_t ld, int64_t row_base, int row0,
+                                                 int nrows, int col0, int d, int wave, int nw, int lane) {
+        for (int p = wave; p < PIECES; p += nw) {          // wave-uniform
+            const int off = p * 256 + 4 * lane;
+            const int row = off / DP, pos = (off % DP) >> 2;
+            const int g = pos ^ (row & 7);
+            const int grow = min(row0 + row, nrows - 1), gcol = min(4 * g, d - 4);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (row_base + grow) * ld + col0 + gcol), (lds_ptr_t)(S + p * 256), 16, 0, 0);
+        }
     }
+    __device__ static __forceinline__ float4 row4(const float* S, int row, int gq) {
+        return *reinterpret_cast<const float4*>(S + row * DP + 4 * (gq ^ (row & 7)));
+    }
+    __device__ static __forceinline__ float elem(const float* S, int row, int col) {
+        return S[row * DP + 4 * ((col >> 2) ^ (row & 7)) + (col & 3)];
+    }
+};
+
+// Per-lane LDS offsets, computed once per kernel: the swizzle only touches the low 3 granule bits, so every fragment read
+// becomes (one of a few lane-constant bases) + (compile-time immediate).
+struct LaneOff {
+    int rows[8];   // rows[u]  : float offset of granule (u ^ (l31&7)) of row l31                      -> mma_rows
+    int cols[4];   // cols[u]  : float offset of column l31 in a row whose (row & 7) == ((u + 4*half) & 7), incl. 4*half rows -> mma_cols
+};
+template <int DP>
+__device__ __forceinline__ LaneOff make_lane_off(int l31, int half) {
+    LaneOff o;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o.rows[u] = l31 * DP + 4 * ((half * (DP / 8) + u) ^ (l31 & 7));   // (for DP = 32 the half bit is swizzled too)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o.cols[u] = (u + 4 * half) * DP + 4 * ((l31 >> 2) ^ ((u + 4 * half) & 7)) + (l31 & 3);
+    return o;
 }
 
-// per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1
+// per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1 (zero past nrows / past d)
 template <int DP>
 __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __restrict__ base, int64_t ld, int64_t row_base,
                                              int row, int nrows, int col0, int d, int half) {
@@ -74,15 +108,15 @@ __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __
 }
 
 // acc (32x32) = Xs-tile (rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T
-template <int DP, int LD>
-__device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], int l31, int half) {
+template <int DP>
+__device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* xr = Xs + l31 * LD + half * (DP / 2);
 #pragma unroll
     for (int s4 = 0; s4 < DP / 2; s4 += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(xr + s4);
+        // granule index within the half = s4/4; its low 3 bits are swizzled (lane-constant table), the rest is an immediate
+        const float4 x = *reinterpret_cast<const float4*>(Xs + lo.rows[(s4 >> 2) & 7] + ((s4 >> 2) & ~7) * 4);
         acc = MFMA(x.x, R[s4], acc);
         acc = MFMA(x.y, R[s4 + 1], acc);
         acc = MFMA(x.z, R[s4 + 2], acc);
@@ -92,14 +126,15 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 }
 
 // acc[c] (dcol x lane-col) += Xs^T (rows = dcol, contraction over the 32 tile rows in krow order) . P (own registers)
-template <int DP, int LD>
-__device__ __forceinline__ void mma_cols(f32x16 (&acc)[DP / 32], const float* __restrict__ Xs, const float (&P)[16], int l31,
-                                         int half, int d) {
+template <int DP>
+__device__ __forceinline__ void mma_cols(f32x16 (&acc)[DP / 32], const float* __restrict__ Xs, const float (&P)[16],
+                                         const LaneOff& lo, int d) {
 #pragma unroll
     for (int c = 0; c < DP / 32; ++c) {
         if (c * 32 < d) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c] = MFMA(Xs[krow(r, half) * LD + c * 32 + l31], P[r], acc[c]);
+            for (int r = 0; r < 16; ++r)     // row = (r&3) + 8*(r>>2) + 4*half: (row&7) only depends on (r&3, half)
+                acc[c] = MFMA(Xs[lo.cols[r & 3] + 8 * (r >> 2) * DP + c * 32], P[r], acc[c]);
         }
     }
 }
@@ -119,23 +154,32 @@ __device__ __forceinline__ void store_cols(const f32x16 (&acc)[DP / 32], float* 
         }
 }
 
+#define TILE_WAIT_AND_SYNC()                                   \
+    do {                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_s_barrier();                          \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------------------------
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-    constexpr int LDK = DP + 4;
+    constexpr int TS = 32 * DP;                 // floats per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;              // [32][LDK]
-    float* Vs = Ks + 32 * LDK;     // [32][DP]
-    float* Ms = Vs + 32 * DP;      // [32] additive mask of the tile (-inf past Tk)
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    // [stage0: K V][stage1: K V][mask row, -inf past Tk]
+    float* Mrow = smem + 4 * TS;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y;
-    const int qi = (blockIdx.x * (nthr >> 6) + wave) * 32 + l31;
+    const int qi = (blockIdx.x * nw + wave) * 32 + l31;
     const bool qvalid = qi < a.Tq;
     const int col0 = h * a.d;
+    const int ntiles = (a.Tk + 31) >> 5;
+    const LaneOff lo = make_lane_off<DP>(l31, half);
 
     float Qr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+    for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[(int64_t)n * a.Tk + j] : 0.f) : -INFINITY;
 
     f32x16 O[DP / 32];
 #pragma unroll
@@ -146,54 +190,64 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 
     DropKey key = {0, 0, 0, 0};
     uint32_t thr = 0; float ik = 1.f;
-    const int64_t tk4 = (a.Tk + 3) >> 2;
-    const int64_t drow = (((int64_t)n * a.heads + h) * a.Tq + qi) * tk4;
+    const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));      // score row id; element = (row id, key)
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
-    for (int j0 = 0; j0 < a.Tk; j0 += 32) {
-        __syncthreads();
-        stage_tile<DP, LDK>(Ks, a.k, a.ldk, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
-        stage_tile<DP, DP>(Vs, a.v, a.ldv, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
-        if (tid < 32) Ms[tid] = (j0 + tid < a.Tk) ? (a.mask ? a.mask[(int64_t)n * a.Tk + j0 + tid] : 0.f) : -INFINITY;
-        __syncthreads();
+    auto issue = [&](int t) {
+        float* st = smem + (t & 1) * 2 * TS;
+        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+    };
+    issue(0);
+    for (int t = 0; t < ntiles; ++t) {
+        TILE_WAIT_AND_SYNC();                      // tile t landed for everyone; everyone finished reading the other stage
+        if (t + 1 < ntiles) issue(t + 1);
+        const float* Ks = smem + (t & 1) * 2 * TS;
+        const float* Vs = Ks + TS;
+        const int j0 = t * 32;
 
-        const f32x16 S = mma_rows<DP, LDK>(Ks, Qr, l31, half);
+        const f32x16 S = mma_rows<DP>(Ks, Qr, lo);
         float P[16];
         float mt = -INFINITY;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 mk = *reinterpret_cast<const float4*>(Ms + 8 * g + 4 * half);
+            const float4 mk = *reinterpret_cast<const float4*>(Mrow + j0 + 8 * g + 4 * half);
             P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
             P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, P[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mn = fmaxf(m, mt);
-        const float alpha = expf(m - mn);
+        // Online softmax with a lazily moved reference point: the running reference m only moves (and O, l are only
+        // rescaled -- 64 accumulator registers through the VALU) when some row's tile maximum exceeds it by more than
+        // RESCALE_THR.  Mathematically identical (any reference cancels in O / l); exp arguments stay <= RESCALE_THR.
+        if (__any(mt > m + RESCALE_THR)) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = __expf(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int c = 0; c < DP / 32; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        }
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { P[r] = expf(P[r] - mn); ps += P[r]; }
+        for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
         ps += __shfl_xor(ps, 32, 64);
-        l = l * alpha + ps;
-        m = mn;
-#pragma unroll
-        for (int c = 0; c < DP / 32; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        l += ps;
         if (DROP) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const u32x4 b = drop_bits(key, (uint64_t)(drow + ((j0 + 8 * g + 4 * half) >> 2)));
-                P[4 * g] = b.x >= thr ? P[4 * g] * ik : 0.f; P[4 * g + 1] = b.y >= thr ? P[4 * g + 1] * ik : 0.f;
-                P[4 * g + 2] = b.z >= thr ? P[4 * g + 2] * ik : 0.f; P[4 * g + 3] = b.w >= thr ? P[4 * g + 3] * ik : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t bits = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key);
+                P[r] = bits >= thr ? P[r] * ik : 0.f;
             }
         }
-        mma_cols<DP, DP>(O, Vs, P, l31, half, a.d);
+        mma_cols<DP>(O, Vs, P, lo, a.d);
     }
     if (qvalid) {
         store_cols<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq + qi, col0, a.d, half, 1.0f / l);
-        if (half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
+        if (half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);   // lse is reference-independent
     }
 }
 
@@ -218,17 +272,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
-    constexpr int LDK = DP + 4;
+    constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;              // [32][LDK]
-    float* Vs = Ks + 32 * LDK;     // [32][LDK]
-    float* Ms = Vs + 32 * LDK;     // [32]
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    float* Mrow = smem + 4 * TS;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y;
-    const int qi = (blockIdx.x * (nthr >> 6) + wave) * 32 + l31;
+    const int qi = (blockIdx.x * nw + wave) * 32 + l31;
     const bool qvalid = qi < a.Tq;
     const int col0 = h * a.d;
+    const int ntiles = (a.Tk + 31) >> 5;
+    const LaneOff lo = make_lane_off<DP>(l31, half);
 
     float Qr[DP / 2], Gr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
@@ -236,6 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
     const float lse = qvalid ? a.lse[sidx] : 0.f;
     const float dl = qvalid ? a.delta[sidx] : 0.f;
+    for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[(int64_t)n * a.Tk + j] : 0.f) : -INFINITY;
 
     f32x16 dQ[DP / 32];
 #pragma unroll
@@ -245,59 +301,69 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 
     DropKey key = {0, 0, 0, 0};
     uint32_t thr = 0; float ik = 1.f;
-    const int64_t tk4 = (a.Tk + 3) >> 2;
-    const int64_t drow = sidx * tk4;
+    const uint32_t dlo = (uint32_t)sidx;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
-    for (int j0 = 0; j0 < a.Tk; j0 += 32) {
-        __syncthreads();
-        stage_tile<DP, LDK>(Ks, a.k, a.ldk, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
-        stage_tile<DP, LDK>(Vs, a.v, a.ldv, (int64_t)n * a.Tk, j0, a.Tk, col0, a.d, tid, nthr);
-        if (tid < 32) Ms[tid] = (j0 + tid < a.Tk) ? (a.mask ? a.mask[(int64_t)n * a.Tk + j0 + tid] : 0.f) : -INFINITY;
-        __syncthreads();
+    auto issue = [&](int t) {
+        float* st = smem + (t & 1) * 2 * TS;
+        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+    };
+    issue(0);
+    for (int t = 0; t < ntiles; ++t) {
+        TILE_WAIT_AND_SYNC();
+        if (t + 1 < ntiles) issue(t + 1);
+        const float* Ks = smem + (t & 1) * 2 * TS;
+        const float* Vs = Ks + TS;
+        const int j0 = t * 32;
 
-        const f32x16 S = mma_rows<DP, LDK>(Ks, Qr, l31, half);
-        const f32x16 dP = mma_rows<DP, LDK>(Vs, Gr, l31, half);
+        const f32x16 S = mma_rows<DP>(Ks, Qr, lo);
+        const f32x16 dP = mma_rows<DP>(Vs, Gr, lo);
         float dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 mk = *reinterpret_cast<const float4*>(Ms + 8 * g + 4 * half);
+            const float4 mk = *reinterpret_cast<const float4*>(Mrow + j0 + 8 * g + 4 * half);
             const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
-            u32x4 b = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (DROP) b = drop_bits(key, (uint64_t)(drow + ((j0 + 8 * g + 4 * half) >> 2)));
-            const uint32_t bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = 4 * g + u;
-                const float p = expf(score(S[r], a.scale, mkv[u]) - lse);
-                const float dp = DROP ? (bb[u] >= thr ? dP[r] * ik : 0.f) : dP[r];
+                const float p = __expf(score(S[r], a.scale, mkv[u]) - lse);
+                float dp = dP[r];
+                if (DROP) dp = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key) >= thr ? dp * ik : 0.f;
                 dS[r] = p * (dp - dl);
             }
         }
-        mma_cols<DP, LDK>(dQ, Ks, dS, l31, half, a.d);
+        mma_cols<DP>(dQ, Ks, dS, lo, a.d);
     }
     if (qvalid) store_cols<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq + qi, col0, a.d, half, a.scale);
 }
 
 template <int DP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
-    constexpr int LDK = DP + 4;
+    constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;               // [32][LDK]  query tile
-    float* Gs = Qs + 32 * LDK;      // [32][LDK]  dctx tile
-    float* Ls = Gs + 32 * LDK;      // [32] lse   (+inf past Tq -> p = 0)
-    float* Ds = Ls + 32;            // [32] delta
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    // [stage0: Q dO][stage1: Q dO][lse row, +inf past Tq][delta row]
+    const int nqt = (a.Tq + 31) >> 5;
+    float* Lrow = smem + 4 * TS;
+    float* Drow = Lrow + nqt * 32;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y;
-    const int kj = (blockIdx.x * (nthr >> 6) + wave) * 32 + l31;    // this lane's key
+    const int kj = (blockIdx.x * nw + wave) * 32 + l31;    // this lane's key
     const bool kvalid = kj < a.Tk;
     const int col0 = h * a.d;
+    const LaneOff lo = make_lane_off<DP>(l31, half);
 
     float Kr[DP / 2], Vr[DP / 2];
     load_rowfrag<DP>(Kr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
     load_rowfrag<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
     const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
+    const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
+    for (int j = tid; j < nqt * 32; j += nthr) {
+        Lrow[j] = j < a.Tq ? a.lse[srow + j] : INFINITY;
+        Drow[j] = j < a.Tq ? a.delta[srow + j] : 0.f;
+    }
 
     f32x16 dK[DP / 32], dV[DP / 32];
 #pragma unroll
@@ -307,46 +373,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 
     DropKey key = {0, 0, 0, 0};
     uint32_t thr = 0; float ik = 1.f;
-    const int64_t tk4 = (a.Tk + 3) >> 2;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
-    const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
 
-    for (int i0 = 0; i0 < a.Tq; i0 += 32) {
-        __syncthreads();
-        stage_tile<DP, LDK>(Qs, a.q, a.ldq, (int64_t)n * a.Tq, i0, a.Tq, col0, a.d, tid, nthr);
-        stage_tile<DP, LDK>(Gs, a.dctx, a.ldo, (int64_t)n * a.Tq, i0, a.Tq, col0, a.d, tid, nthr);
-        if (tid < 32) {
-            const bool ok = i0 + tid < a.Tq;
-            Ls[tid] = ok ? a.lse[srow + i0 + tid] : INFINITY;
-            Ds[tid] = ok ? a.delta[srow + i0 + tid] : 0.f;
-        }
-        __syncthreads();
+    auto issue = [&](int t) {
+        float* st = smem + (t & 1) * 2 * TS;
+        Tile<DP>::issue(st, a.q, a.ldq, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.dctx, a.ldo, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+    };
+    issue(0);
+    for (int t = 0; t < nqt; ++t) {
+        TILE_WAIT_AND_SYNC();
+        if (t + 1 < nqt) issue(t + 1);
+        const float* Qs = smem + (t & 1) * 2 * TS;
+        const float* Gs = Qs + TS;
+        const int i0 = t * 32;
 
         // S[query][key] and dP[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
-        const f32x16 S = mma_rows<DP, LDK>(Qs, Kr, l31, half);
-        const f32x16 dP = mma_rows<DP, LDK>(Gs, Vr, l31, half);
+        const f32x16 S = mma_rows<DP>(Qs, Kr, lo);
+        const f32x16 dP = mma_rows<DP>(Gs, Vr, lo);
         float Pt[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 ls = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * half);
-            const float4 ds = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * half);
+            const float4 ls = *reinterpret_cast<const float4*>(Lrow + i0 + 8 * g + 4 * half);
+            const float4 ds = *reinterpret_cast<const float4*>(Drow + i0 + 8 * g + 4 * half);
             const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = 4 * g + u;
-                const float p = expf(score(S[r], a.scale, mk) - lsv[u]);
+                const float p = __expf(score(S[r], a.scale, mk) - lsv[u]);
                 float keep = 1.f;
-                if (DROP) {
-                    const int qq = i0 + 8 * g + 4 * half + u;
-                    const uint64_t e = (uint64_t)((srow + qq) * tk4) * 4ull + (uint64_t)kj;
-                    keep = drop_scale1(key, e, thr, ik);
-                }
+                if (DROP) keep = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + 8 * g + 4 * half + u), key) >= thr ? ik : 0.f;
                 Pt[r] = p * keep;
                 dS[r] = p * (dP[r] * keep - dsv[u]);
             }
         }
-        mma_cols<DP, LDK>(dV, Gs, Pt, l31, half, a.d);
-        mma_cols<DP, LDK>(dK, Qs, dS, l31, half, a.d);
+        mma_cols<DP>(dV, Gs, Pt, lo, a.d);
+        mma_cols<DP>(dK, Qs, dS, lo, a.d);
     }
     if (kvalid) {
         store_cols<DP>(dV, a.dv, a.lddv, (int64_t)n * a.Tk + kj, col0, a.d, half, 1.0f);
@@ -370,7 +432,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict
         const float* kp = k + (n * Tk + j) * ldk + h * d;
         float acc = 0.f;
         for (int c = 0; c < d; ++c) acc = fmaf(qp[c], kp[c], acc);
-        probs[i] = expf(score(acc, scale, mask ? mask[n * Tk + j] : 0.f) - lse[(n * heads + h) * Tq + qi]);
+        probs[i] = __expf(score(acc, scale, mask ? mask[n * Tk + j] : 0.f) - lse[(n * heads + h) * Tq + qi]);
     }
 }
 
@@ -411,8 +473,9 @@ static int check_common(const char* who, const AttnArgs& a) {
         }                                                                                                    \
     } while (0)
 
-static size_t lds_fwd(int dp) { return (size_t)(32 * (dp + 4) + 32 * dp + 32) * sizeof(float); }
-static size_t lds_bwd(int dp) { return (size_t)(2 * 32 * (dp + 4) + 64) * sizeof(float); }
+static int g_rows = 0;     // length of the streamed dimension (mask / lse rows staged whole in LDS); set before each dispatch
+static size_t lds_fwd(int dp) { return (size_t)(4 * 32 * dp + ((g_rows + 31) / 32) * 32) * sizeof(float); }
+static size_t lds_bwd(int dp) { return (size_t)(4 * 32 * dp + 2 * ((g_rows + 31) / 32) * 32) * sizeof(float); }
 
 }  // namespace ytvln
 
@@ -430,6 +493,8 @@ extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, i
     const int nw = pick_waves(Tq);
     dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
     hipStream_t s = as_stream(stream);
+    YT_REQUIRE(Tk <= 8192 && Tq <= 8192, "attn_fwd: sequence too long for the LDS-resident mask row");
+    g_rows = Tk;
     DISPATCH_DP_DROP(attn_fwd_kernel, grid, block, lds_fwd, s, a);
     YT_LAUNCH_CHECK("attn_fwd");
     return 0;
@@ -447,6 +512,7 @@ extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, i
     a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
     if (int rc = check_common("attn_bwd", a)) return rc;
     YT_REQUIRE(ctx && dctx && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
+    YT_REQUIRE(Tk <= 8192 && Tq <= 8192, "attn_bwd: sequence too long for the LDS-resident mask / lse rows");
     YT_REQUIRE(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: gradient leading dimensions must be multiples of 4");
     YT_REQUIRE((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0, "attn_bwd: misaligned pointer");
     hipStream_t s = as_stream(stream);
@@ -456,11 +522,13 @@ extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, i
     {
         const int nw = pick_waves(Tq);
         dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
-        DISPATCH_DP_DROP(attn_bwd_dq_kernel, grid, block, lds_bwd, s, a);
+        g_rows = Tk;
+        DISPATCH_DP_DROP(attn_bwd_dq_kernel, grid, block, lds_fwd, s, a);
     }
     {
         const int nw = pick_waves(Tk);
         dim3 grid((unsigned)cdiv(Tk, 32 * nw), heads, N), block(64 * nw);
+        g_rows = Tq;
         DISPATCH_DP_DROP(attn_bwd_dkv_kernel, grid, block, lds_bwd, s, a);
     }
     YT_LAUNCH_CHECK("attn_bwd");

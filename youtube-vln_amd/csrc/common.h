@@ -67,6 +67,15 @@ __device__ __forceinline__ float drop_scale1(const DropKey& k, uint64_t e, uint3
     return sel >= thr ? inv_keep : 0.0f;
 }
 
+// Cheap per-element keep decision for attention-probability dropout: murmur3 finaliser over (element index, key).  One
+// 32-bit hash per score, the same in every fragment layout (the forward / dQ kernels hold 4 consecutive keys per lane, the
+// dK/dV kernel 4 consecutive queries), ~8 VALU ops instead of a 10-round Philox call.
+__device__ __forceinline__ uint32_t attn_drop_hash(uint32_t lo, uint32_t hi, const DropKey& k) {
+    uint32_t x = (lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u) ^ k.k0;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x += k.k1 ^ k.s0; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
 // ---- wave / block reductions ------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
