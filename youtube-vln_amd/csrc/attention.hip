@@ -162,7 +162,7 @@ __device__ __forceinline__ void store_cols(const f32x16 (&acc)[DP / 32], float* 
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int DP, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int TS = 32 * DP;                 // floats per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage0: K V][stage1: K V][mask row, -inf past Tk]
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 template <int DP, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Mrow = smem + 4 * TS;
