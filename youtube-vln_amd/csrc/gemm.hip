@@ -415,6 +415,9 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         const int var = ev ? atoi(ev) : 0;
         // 128x128 tiles run 8 waves per workgroup (4 per SIMD at 2 workgroups/CU): measured 113 -> 121 TFLOP/s on
         // 16128x1024x1024 and 84 -> 105 on the split-K weight gradients versus 4 waves (barrier coupling across SIMDs).
+        // (Measured and rejected: 256x128 tiles at one workgroup per CU -- lower steady state and more fixed cost; removing
+        //  the per-tile barrier changes nothing, while removing the operand DMA lifts steady state 130 -> 147 TFLOP/s, i.e. the
+        //  residual gap to the MFMA peak is operand traffic, not synchronisation.  See DESIGN.md section 5.)
         if constexpr (BM == 128 && BN == 128) {
             if (var == 4) YT_DMA(0, 4);
             else YT_DMA(0, 8);
@@ -427,10 +430,12 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
 #undef YT_DMA
         return 0;
     }
-    if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
+    if constexpr (BM <= 128) {
+        if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
+    }
     return 0;
 }
 
