@@ -155,12 +155,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.set_num_threads(effective_cores())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # (ranks may share a device only in the gloo self-test below)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  YTVLN_DIST_BACKEND=gloo exists only to exercise the data-parallel code path with several
+        # ranks on ONE GPU (RCCL refuses duplicate devices); it is never a measurement configuration.
+        backend = os.environ.get("YTVLN_DIST_BACKEND", "nccl")
+        if backend == "nccl" and world > ndev:
+            raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev})")
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
 
     from ytvln import synth, utils_init
     from ytvln.distributed import DataParallel
@@ -226,7 +233,7 @@ def main():
         "metric": "pretrain samples/sec (traj-instr pairs)", "value": round(value, 3), "unit": "pairs/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * elapsed / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": a.workload, "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
+        "config": {"workload": a.workload, **({"dist_backend": os.environ["YTVLN_DIST_BACKEND"]} if "YTVLN_DIST_BACKEND" in os.environ else {}), "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
                    "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
                    "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
                    "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}"},
