@@ -388,13 +388,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// split-K plan: only for plain (no activation) GEMMs whose 128x128 tiling cannot fill the chip
+// split-K plan: only for plain (no activation) GEMMs whose 128x128 tiling cannot fill the chip.  256 CUs hold 512 resident
+// 128x128 workgroups; pick the split count whose tiles x splits best fills whole rounds of 512 (fewest splits on ties), with
+// at least 8 k-tiles per split.
 static int plan_splits(int M, int N, int K, int epilogue) {
     if (epilogue != YTVLN_EPI_NONE) return 1;
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
     if (tiles >= 384 || K < 1024) return 1;
-    int splits = (int)std::min<int64_t>(cdiv(640, tiles), K / 256);
-    return std::max(1, std::min(splits, 64));
+    const int smax = (int)std::min<int64_t>(64, K / 256);
+    int best = 1;
+    double best_eff = (double)tiles / (double)(cdiv(tiles, 512) * 512);
+    for (int sp = 2; sp <= smax; ++sp) {
+        const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
+        const int64_t blocks = tiles * cdiv(K, kchunk);
+        const double eff = (double)blocks / (double)(cdiv(blocks, 512) * 512);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    return best;
 }
 
 template <int BM, int BN>

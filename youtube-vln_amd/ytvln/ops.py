@@ -103,9 +103,11 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
 
 def colsum(x: Tensor, M: int, N: int, ld: int) -> Tensor:
     """Deterministic column sums of the [M, N] matrix at x (leading dimension ld) -> [N]."""
+    first = True
     while True:
         nstrips = (N + 63) // 64
-        nb = max(1, min((M + 31) // 32, max(1, 2048 // nstrips)))
+        nb = max(1, min((M + 31) // 32, max(1, 2048 // nstrips))) if first else 1      # two stages at most
+        first = False
         rpb = (M + nb - 1) // nb
         nb = (M + rpb - 1) // rpb
         out = torch.empty((nb, N), dtype=torch.float32, device=x.device)
