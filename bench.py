@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--bs", type=int, default=None, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the training step as one captured hipGraph (single-GPU runs)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-shape GEMM timing to stderr")
     ap.add_argument("--eval-dropout-off", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -204,16 +206,48 @@ def main():
     def step(i):
         return utils_init.train_step(runner, opt, sched, batch, args, i, all_options=True)
 
+    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1)
+    execution = "eager launches"
+    eager_step = step
+    if use_graph:
+        # hipGraph replay of the whole step (forward, losses, backward, fused AdamW): the host only uploads the LR-dependent
+        # hyper-parameters and advances the schedule.  Dropout masks still change every replay (device-side counter).
+        assert world == 1, "--graph is a single-GPU mode"
+        try:
+            for i in range(2):                                 # eager steps: build the optimizer arenas, warm the allocator
+                eager_step(i)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            static = {}
+            with torch.cuda.graph(graph):
+                static["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True)
+            torch.cuda.synchronize()
+
+            def step(i):   # noqa: F811
+                opt.prepare_replay()
+                graph.replay()
+                sched.step()
+                return static["loss"], None
+
+            execution = "hipGraph replay of the captured step"
+        except Exception as e:   # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            opt.zero_grad()
+            use_graph = False
+            step = eager_step
+
     for i in range(a.warmup):
         loss, _ = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = True
+    timer.on = not use_graph             # graph replays cannot bracket single kernels: see the eager pass below
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss, _ = step(a.warmup + i)
+    host_enqueue = time.perf_counter() - t0          # host time to enqueue the timed steps (before the device drains)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -226,6 +260,15 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss)
     assert np.isfinite(final_loss), "training diverged"
+    roofline_note = "HIP events around every GEMM launch during the timed steps"
+    if use_graph and not a.no_kernel_timing:
+        n_prof = min(a.steps, 3)
+        timer.on = True
+        for i in range(n_prof):
+            eager_step(a.warmup + a.steps + i)
+        torch.cuda.synchronize()
+        timer.on = False
+        roofline_note = f"HIP events around every GEMM launch during {n_prof} eager steps run right after the timed graph replays"
 
     pairs_per_step = bs * K * world
     value = pairs_per_step * a.steps / elapsed
@@ -236,8 +279,10 @@ def main():
         "config": {"workload": a.workload, **({"dist_backend": os.environ["YTVLN_DIST_BACKEND"]} if "YTVLN_DIST_BACKEND" in os.environ else {}), "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
                    "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
                    "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
-                   "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}"},
+                   "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}",
+                   "execution": execution},
         "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
+        "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / a.steps, 2),
     }
     if "full" in a.workload and T == 80 and frames * boxes == 288:
         out["model_tflops"] = round(value * TRAIN_GFLOP_PER_PAIR / 1000.0, 2)
@@ -248,7 +293,7 @@ def main():
         out["roofline"] = {"kernel": "ytvln::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                            "traffic": None, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
-                           "avg_launch_gflop": round(flop / n / 1e9, 3), "gemm_time_share": round(ms / (1000.0 * elapsed), 4)}
+                           "avg_launch_gflop": round(flop / n / 1e9, 3), "measured": roofline_note}
         if a.kernel_table and rank == 0:
             rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
             print(f"{'M':>7} {'N':>6} {'K':>6} tA tB {'calls':>6} {'ms':>9} {'TF/s':>7}", file=sys.stderr)

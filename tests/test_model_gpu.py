@@ -282,3 +282,39 @@ def test_training_mode_dropout_runs_and_is_reproducible(dev, lib):
     with torch.no_grad():
         _, total_eval, _ = losses_of(model, batch, args)
     assert abs(float(total_eval) - res[0][0]) > 1e-6
+
+
+def test_graph_replay_equals_eager(dev, lib):
+    """A training step captured once into a hipGraph and replayed must produce the same parameters as eager launches."""
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0), dev)
+    finals, losses = [], []
+    for mode in ("eager", "graph"):
+        model, _ = build_lily(dev, "micro.json", args, seed=11)
+        model.train()
+        opt, sched, _, _ = get_optimization(args, model, 10, None)
+        for i in range(2):
+            U.train_step(model, opt, sched, batch, args, i, all_options=True)
+        if mode == "eager":
+            for i in range(2, 5):
+                loss, _ = U.train_step(model, opt, sched, batch, args, i, all_options=True)
+        else:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, _ = U.train_step(model, opt, None, batch, args, 0, all_options=True)
+            for i in range(2, 5):
+                opt.prepare_replay()
+                g.replay()
+                sched.step()
+        torch.cuda.synchronize()
+        finals.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+        losses.append(float(loss))
+        assert all(opt.state[p]["step"] == 5 for p in model.parameters() if p in opt.state and "step" in opt.state[p])
+    assert abs(losses[0] - losses[1]) < 1e-6, losses
+    # (not bit-equal: the word-embedding gradient is an atomic scatter-add whose summation order varies run to run)
+    assert float((finals[0] - finals[1]).abs().max()) < 2e-6, float((finals[0] - finals[1]).abs().max())

@@ -101,8 +101,9 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
          M, N, K, epi, float(beta), _ptr(ws), need, _stream())
 
 
-def colsum(x: Tensor, M: int, N: int, ld: int) -> Tensor:
-    """Deterministic column sums of the [M, N] matrix at x (leading dimension ld) -> [N]."""
+def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> Tensor:
+    """Deterministic column sums of the [M, N] matrix at x (leading dimension ld) -> [N] (written into `out` if given,
+    e.g. a gradient-arena slot)."""
     first = True
     while True:
         nstrips = (N + 63) // 64
@@ -110,11 +111,13 @@ def colsum(x: Tensor, M: int, N: int, ld: int) -> Tensor:
         first = False
         rpb = (M + nb - 1) // nb
         nb = (M + rpb - 1) // rpb
-        out = torch.empty((nb, N), dtype=torch.float32, device=x.device)
-        call("ytvln_colsum_f32", _ptr(x), ld, M, N, _ptr(out), N, rpb, _stream())
         if nb == 1:
-            return out[0]
-        x, M, ld = out, nb, N
+            res = out if out is not None else torch.empty(N, dtype=torch.float32, device=x.device)
+            call("ytvln_colsum_f32", _ptr(x), ld, M, N, _ptr(res), N, rpb, _stream())
+            return res
+        part = torch.empty((nb, N), dtype=torch.float32, device=x.device)
+        call("ytvln_colsum_f32", _ptr(x), ld, M, N, _ptr(part), N, rpb, _stream())
+        x, M, ld = part, nb, N
 
 
 def colsum_by_index(x: Tensor, M: int, N: int, ld: int, KT: int, idx_f32: Optional[Tensor] = None, idx_stride: int = 1,
@@ -130,6 +133,94 @@ def colsum_by_index(x: Tensor, M: int, N: int, ld: int, KT: int, idx_f32: Option
     if nb == 1:
         return out[0]
     return colsum(out, nb, KT * N, KT * N).view(KT, N)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# flat-arena hooks (registered by ytvln.optimization.AdamW once parameters / gradients live in flat arenas)
+# ------------------------------------------------------------------------------------------------------------------
+class ArenaSlot:
+    """Where a parameter lives inside the optimizer's flat arenas.  Attached to the Parameter object as `_ytvln_slot` by
+    ytvln.optimization.AdamW; `written` (shared per arena) records which gradient slots a GEMM has already written directly
+    since the last optimizer step / zero_grad, so a weight used twice before one backward falls back to the additive path."""
+    __slots__ = ("flat_p", "flat_g", "off", "numel", "written")
+
+    def __init__(self, flat_p, flat_g, off, numel, written):
+        self.flat_p, self.flat_g, self.off, self.numel, self.written = flat_p, flat_g, off, numel, written
+
+    def valid_for(self, t) -> bool:
+        return t.numel() == self.numel and t.data_ptr() == self.flat_p.data_ptr() + 4 * self.off
+
+
+def _slot_of(t):
+    sl = getattr(t, "_ytvln_slot", None)
+    return sl if (sl is not None and sl.valid_for(t)) else None
+
+
+def _targets_of(weight):
+    """The parameters a weight operand stands for: itself, or the members of a packed (concatenated) view."""
+    if isinstance(weight, torch.nn.Parameter):
+        return (weight,)
+    return getattr(weight, "_ytvln_pack_params", None)
+
+
+def _direct_grad(targets, shape):
+    """A fresh view of the flat gradient arena covering `targets` (adjacent there, none of them holding a gradient yet and
+    none written directly since the last step), shaped `shape` -- the weight-gradient GEMM then writes its result straight
+    into the arena and autograd's AccumulateGrad adopts the view without a copy or a read-modify-write pass.  None when the
+    conditions do not hold (the caller then allocates a normal gradient tensor)."""
+    if not targets:
+        return None
+    first = _slot_of(targets[0])
+    if first is None:
+        return None
+    off = first.off
+    for t in targets:
+        sl = _slot_of(t)
+        if sl is None or sl.flat_g is not first.flat_g or sl.off != off or t.grad is not None or sl.off in sl.written:
+            return None
+        off += sl.numel
+    for t in targets:
+        first.written.add(t._ytvln_slot.off)
+    return first.flat_g[first.off:off].view(shape)
+
+
+class PackRowsFn(torch.autograd.Function):
+    """cat(params, dim=0) for the packed Q|K|V (or K|V) projection.  Once the optimizer has moved the parameters into its
+    flat arena the members are adjacent in memory and the packed operand is a zero-copy view; the backward hands each member
+    its row block of the packed gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ctx.set_materialize_grads(False)
+        ctx.rows = [t.shape[0] for t in ts]
+        first = _slot_of(ts[0])
+        if first is not None:
+            off, ok = first.off, True
+            for t in ts:
+                sl = _slot_of(t)
+                if sl is None or sl.flat_p is not first.flat_p or sl.off != off:
+                    ok = False
+                    break
+                off += sl.numel
+            if ok:
+                return first.flat_p[first.off:off].view((sum(ctx.rows),) + tuple(ts[0].shape[1:]))
+        return torch.cat([t.detach() for t in ts], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * len(ctx.rows)
+        out, r0 = [], 0
+        for r in ctx.rows:
+            out.append(g.narrow(0, r0, r))
+            r0 += r
+        return tuple(out)
+
+
+def pack_rows(*params):
+    w = PackRowsFn.apply(*params)
+    w._ytvln_pack_params = tuple(params)
+    return w
 
 
 class LinearFn(torch.autograd.Function):
@@ -151,6 +242,8 @@ class LinearFn(torch.autograd.Function):
         _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, N, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
         ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
         ctx.in_shape = x.shape
+        ctx.targets = _targets_of(weight)
+        ctx.btargets = _targets_of(bias) if bias is not None else None
         ctx.save_for_backward(x2, weight, z if epi == EPI_GELU else (y if epi == EPI_RELU else None))
         return y.view(*x.shape[:-1], N)
 
@@ -173,10 +266,12 @@ class LinearFn(torch.autograd.Function):
             _gemm(dy, N, 0, weight, weight.stride(0), 0, dx, K, M, K, N)
             dx = dx.view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            dw = _direct_grad(ctx.targets, (N, K))
+            if dw is None:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             _gemm(dy, N, 1, x2, ctx.lda, 0, dw, K, N, K, M)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, M, N, N)
+            db = colsum(dy, M, N, N, out=_direct_grad(ctx.btargets, (N,)))
         return dx, dw, db, None
 
 
@@ -200,6 +295,7 @@ class FFNFn(torch.autograd.Function):
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2)
         ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
+        ctx.targets = (_targets_of(w1), _targets_of(w2), _targets_of(b1), _targets_of(b2))
         ctx.save_for_backward(x2, w1, w2, z, h)
         return y.view(*x.shape[:-1], N)
 
@@ -215,17 +311,21 @@ class FFNFn(torch.autograd.Function):
         dev = dy.device
         dz = torch.empty((M, I), dtype=torch.float32, device=dev)
         _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU)   # dH * gelu'(z)
-        dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
+        dw2 = _direct_grad(ctx.targets[1], (N, I))
+        if dw2 is None:
+            dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
         _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M)
-        db2 = colsum(dy, M, N, N)
+        db2 = colsum(dy, M, N, N, out=_direct_grad(ctx.targets[3], (N,)))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I)
             dx = dx.view(ctx.in_shape)
-        dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
+        dw1 = _direct_grad(ctx.targets[0], (I, K))
+        if dw1 is None:
+            dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
         _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M)
-        db1 = colsum(dz, M, I, I)
+        db1 = colsum(dz, M, I, I, out=_direct_grad(ctx.targets[2], (I,)))
         return dx, dw1, db1, dw2, db2
 
 
@@ -236,7 +336,7 @@ def ffn(x, w1, b1, w2, b2) -> Tensor:
 # ------------------------------------------------------------------------------------------------------------------
 # LayerNorm family
 # ------------------------------------------------------------------------------------------------------------------
-def _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site):
+def _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site, gb_targets=None):
     dy = dy.reshape(rows, H)
     if not dy.is_contiguous():
         dy = dy.contiguous()
@@ -246,7 +346,7 @@ def _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site):
     partial = torch.empty((nb, 2 * H), dtype=torch.float32, device=dy.device)
     call("ytvln_ln_bwd_f32", _ptr(dy), _ptr(s), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(ds), _ptr(dx), _ptr(partial), rows, H,
          float(p_pre), float(p_post), _ptr(rng) if rng is not None else None, int(site), _stream())
-    gb = colsum(partial, nb, 2 * H, 2 * H)
+    gb = colsum(partial, nb, 2 * H, 2 * H, out=_direct_grad(gb_targets, (2 * H,)))      # LayerNorm.weight | LayerNorm.bias
     return ds, (dx if dx is not None else ds), gb[:H], gb[H:]
 
 
@@ -271,6 +371,7 @@ class AddLayerNormFn(torch.autograd.Function):
         call("ytvln_ln_fwd_f32", _ptr(xc), _ptr(rc), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s), _ptr(mean), _ptr(rstd), rows, H,
              float(eps), float(p_pre), float(p_post), _ptr(rng) if rng is not None else None, int(site), _stream())
         ctx.meta = (rows, H, p_pre, p_post, site, res is not None)
+        ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
         ctx.save_for_backward(s, mean, rstd, gamma, rng)
         return y
 
@@ -280,7 +381,7 @@ class AddLayerNormFn(torch.autograd.Function):
             return (None,) * 9
         s, mean, rstd, gamma, rng = ctx.saved_tensors
         rows, H, p_pre, p_post, site, has_res = ctx.meta
-        ds, dx, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site)
+        ds, dx, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site, ctx.gb)
         shape = dy.shape
         return (dx.view(shape) if ctx.needs_input_grad[0] else None,
                 ds.view(shape) if (has_res and ctx.needs_input_grad[1]) else None, dg, db, None, None, None, None, None)

@@ -115,6 +115,12 @@ class AdamW(Optimizer):
         self._arena = dict(flat, index=index, ids=[id(p) for _, p in members])
         self._launch = None
         del old
+        # let the weight-gradient GEMMs write straight into the gradient arena and the packed projections alias the
+        # parameter arena: every member parameter carries its slot (ytvln.ops.ArenaSlot)
+        self._written = set()
+        for _, p in members:
+            o, n = index[id(p)]
+            p._ytvln_slot = ops.ArenaSlot(flat["p"], flat["g"], o, n, self._written)
 
     def _ensure_arena(self):
         members = self._members()
@@ -164,20 +170,9 @@ class AdamW(Optimizer):
         self._launch = launch
 
     # ---- the step -------------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        members = self._ensure_arena()
-        if not members:
-            return loss
-        if self._launch is None or any(self.state[c["params"][0]]["step"] != c["step"] for c in self._launch):
-            self._build_launch(members)
-        a = self._arena
-        if getattr(self, "grad_sync", None) is not None:      # data-parallel gradient exchange (ytvln/distributed.py)
-            self.grad_sync(a["g"], [(p,) + a["index"][id(p)] for _, p in members])
+    def _upload_hyper(self):
+        """Host -> device upload of (beta1, beta2, eps, step_size, lr) for every launch class and advance of the step
+        counters.  Eager by design: under hipGraph replay (`capturing=True` steps) this is the only per-step host work."""
         for c in self._launch:
             g = self.param_groups[c["group"]]
             b1, b2 = g["betas"]
@@ -193,15 +188,56 @@ class AdamW(Optimizer):
             c["hyper"].copy_(host, non_blocking=True)
             c["events"][k] = torch.cuda.Event()
             c["events"][k].record()
-            ops.adamw_step(a["p"], a["g"], a["m"], a["v"], c["table"], c["n"], c["hyper"], self.grad_scale)
             c["step"] = t
             for p in c["params"]:
                 self.state[p]["step"] = t
+
+    def _launch_kernels(self):
+        a = self._arena
+        for c in self._launch:
+            ops.adamw_step(a["p"], a["g"], a["m"], a["v"], c["table"], c["n"], c["hyper"], self.grad_scale)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture of a whole training step: only the device work is recorded; the caller uploads the
+            # hyper-parameters eagerly before every replay (`prepare_replay()`).  The arena must already exist.
+            if self._arena is None or self._launch is None:
+                raise RuntimeError("run at least one eager optimizer step before capturing a step into a graph")
+            if self._arena["ids"] != [id(p) for _, p in self._members()]:
+                raise RuntimeError("the set of parameters receiving gradients changed; cannot capture")
+            self._ensure_arena()          # records the device copies that adopt the few non-arena gradients (embeddings)
+            self._written.clear()
+            self._launch_kernels()
+            return loss
+        members = self._ensure_arena()
+        if not members:
+            return loss
+        if self._launch is None or any(self.state[c["params"][0]]["step"] != c["step"] for c in self._launch):
+            self._build_launch(members)
+        a = self._arena
+        self._written.clear()                                   # gradients are consumed: slots may be written directly again
+        if getattr(self, "grad_sync", None) is not None:      # data-parallel gradient exchange (ytvln/distributed.py)
+            self.grad_sync(a["g"], [(p,) + a["index"][id(p)] for _, p in members])
+        self._upload_hyper()
+        self._launch_kernels()
         return loss
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Zero the flat gradient arena with one memset and keep the views (set_to_none would drop them and cost a
-        re-adoption copy at the next step).  Before the arena exists, behaves like torch's default."""
+    def prepare_replay(self):
+        """Call before each replay of a captured training step (after scheduler.step() set the new learning rate)."""
+        self._upload_hyper()
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Drop the gradients (`p.grad = None`).  With the arena in place the next backward writes weight gradients straight
+        into their arena slots (ytvln.ops._direct_grad) and autograd adopts those views, so no memset and no accumulation
+        pass is needed; the few small tensors that arrive as separate allocations (biases, LayerNorm, embeddings) are
+        copied into their slots at the next step().  `set_to_none=False` zeroes the arena in place and keeps the views."""
+        if self._arena is not None:
+            self._written.clear()
         if self._arena is None or set_to_none:
             return super().zero_grad(set_to_none=True)
         self._arena["g"].zero_()

@@ -77,7 +77,7 @@ def get_loss_correct(batch: List[torch.Tensor], outputs: Dict[str, torch.Tensor]
     unpack = (lambda t: t.view(opt_mask.shape)) if all_options else (lambda t: pad_packed(t, opt_mask))
     batch_size = get_batch_size(batch)
     device = opt_mask.device
-    correct = torch.tensor(0, device=device)
+    correct = torch.zeros((), device=device)        # (device-side fill: safe inside hipGraph capture, unlike a host scalar copy)
     if task == "vision":
         predictions = outputs["vision"]
         predictions = predictions.reshape(-1, predictions.shape[2])
@@ -119,7 +119,7 @@ def compute_metrics_independent(batch, outputs, task, args, logger, reduced_metr
     batch_size, target, loss, correct = get_loss_correct(batch, outputs, task, args, logger, True, all_options)
     reduced_loss = loss.detach().float()
     reduced_correct = correct.detach().float()
-    reduced_batch_size = torch.tensor(batch_size, device=device).float()
+    reduced_batch_size = torch.full((), float(batch_size), device=device)
     if getattr(args, "local_rank", -1) != -1 and not getattr(args, "skip_all_reduce", False) and dist.is_initialized():
         packed = torch.stack([reduced_loss / float(dist.get_world_size()), reduced_correct, reduced_batch_size])
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)          # one small collective instead of the reference's three

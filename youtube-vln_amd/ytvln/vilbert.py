@@ -175,9 +175,7 @@ class _PackedQKV:
 
     @staticmethod
     def project(x, q: nn.Linear, k: nn.Linear, v: nn.Linear):
-        w = torch.cat([q.weight, k.weight, v.weight], dim=0)
-        b = torch.cat([q.bias, k.bias, v.bias], dim=0)
-        return ops.linear(x, w, b)
+        return ops.linear(x, ops.pack_rows(q.weight, k.weight, v.weight), ops.pack_rows(q.bias, k.bias, v.bias))
 
 
 class _SelfAttentionBase(nn.Module):
@@ -377,11 +375,11 @@ class BertBiAttention(nn.Module):
         hb = self.all_head_size
         m1, m2 = _mask2d(attention_mask1, n, r), _mask2d(attention_mask2, n, t)
         q1 = ops.linear(input_tensor1, self.query1.weight, self.query1.bias).view(n * r, hb)
-        kv1 = ops.linear(input_tensor1, torch.cat([self.key1.weight, self.value1.weight], 0),
-                         torch.cat([self.key1.bias, self.value1.bias], 0)).view(n * r, 2 * hb)
+        kv1 = ops.linear(input_tensor1, ops.pack_rows(self.key1.weight, self.value1.weight),
+                         ops.pack_rows(self.key1.bias, self.value1.bias)).view(n * r, 2 * hb)
         q2 = ops.linear(input_tensor2, self.query2.weight, self.query2.bias).view(n * t, hb)
-        kv2 = ops.linear(input_tensor2, torch.cat([self.key2.weight, self.value2.weight], 0),
-                         torch.cat([self.key2.bias, self.value2.bias], 0)).view(n * t, 2 * hb)
+        kv2 = ops.linear(input_tensor2, ops.pack_rows(self.key2.weight, self.value2.weight),
+                         ops.pack_rows(self.key2.bias, self.value2.bias)).view(n * t, 2 * hb)
         p1, p2 = _p(self, self.dropout1.p), _p(self, self.dropout2.p)
         st = _drop_state(self, q1) if (p1 > 0 or p2 > 0) else None
         s1, s2 = (st.next_site(), st.next_site()) if st else (0, 0)
