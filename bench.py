@@ -290,9 +290,16 @@ def main():
     if not a.no_kernel_timing and timer.records:
         ms, flop, n, shapes = timer.summary()
         ach = flop / (ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "ytvln::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 2),
+        traffic, traffic_note = None, None
+        try:     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (cannot be collected in-process)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))
+            traffic = pmc["kernels"]["gemm_dma"]["hbm_side_bytes_per_launch"]
+            traffic_note = "profiles/round1_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
+        except (OSError, KeyError, ValueError):
+            pass
+        out["roofline"] = {"kernel": "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": None, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
+                           "traffic": traffic, "traffic_source": traffic_note, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
                            "avg_launch_gflop": round(flop / n / 1e9, 3), "measured": roofline_note}
         if a.kernel_table and rank == 0:
             rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])

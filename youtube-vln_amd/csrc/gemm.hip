@@ -373,18 +373,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half);
 }
 
-// C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic
+// C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
                                                             const float* __restrict__ bias, int M, int N, int splits, float beta) {
-    const int64_t total = (int64_t)M * N;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int row = (int)(i / N), col = (int)(i % N);
-        float acc = ws[i];
-        for (int s = 1; s < splits; ++s) acc += ws[(int64_t)s * total + i];
-        if (bias) acc += bias[col];
-        float* cp = C + (int64_t)row * ldc + col;
-        if (beta != 0.f) acc += beta * *cp;
-        *cp = acc;
+    const int n4 = (N + 3) >> 2;
+    const int64_t total = (int64_t)M * N, groups = (int64_t)M * n4;
+    const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * 256) {
+        const int row = (int)(gidx / n4), col = (int)(gidx % n4) << 2;
+        const int64_t i = (int64_t)row * N + col;
+        if (vec) {
+            float4 acc = *reinterpret_cast<const float4*>(ws + i);
+            for (int s = 1; s < splits; ++s) {
+                const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * total + i);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (bias) { acc.x += bias[col]; acc.y += bias[col + 1]; acc.z += bias[col + 2]; acc.w += bias[col + 3]; }
+            float4* cp = reinterpret_cast<float4*>(C + (int64_t)row * ldc + col);
+            if (beta != 0.f) { const float4 o = *cp; acc.x += beta * o.x; acc.y += beta * o.y; acc.z += beta * o.z; acc.w += beta * o.w; }
+            *cp = acc;
+        } else {
+            for (int u = 0; u < 4 && col + u < N; ++u) {
+                float acc = ws[i + u];
+                for (int s = 1; s < splits; ++s) acc += ws[(int64_t)s * total + i + u];
+                if (bias) acc += bias[col + u];
+                float* cp = C + (int64_t)row * ldc + col + u;
+                if (beta != 0.f) acc += beta * *cp;
+                *cp = acc;
+            }
+        }
     }
 }
 
@@ -486,7 +503,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     if (g.splits > 1) {
         launch_tile<128, 128>(g, transA, transB, s);
         const int64_t total = (int64_t)M * N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, s, workspace, C,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
                            ldc, bias, M, N, g.splits, beta);
     } else {
         g.splits = 1;
