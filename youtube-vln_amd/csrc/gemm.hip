@@ -24,13 +24,35 @@ struct GemmArgs {
     int epilogue;
     float beta;
     int vecA, vecB;   // 16-byte aligned vector loads legal for the operand
-    int tiles_n, ntiles;
+    int tiles_m, tiles_n, ntiles;
     int splits, kchunk;   // split-K: blockIdx.y owns k in [y*kchunk, (y+1)*kchunk); partial tiles go to ws[y][M][N]
     float* ws;
     int fast;             // LDS-DMA main loop legal (K % 32 == 0, aligned operands, M/N-contiguous extents % 4 == 0)
 };
 
 constexpr int BK = 32;
+
+// Workgroup id -> (tile row, tile column, split).  MI355X dispatches workgroup b to XCD b % 8 and every XCD has its own L2:
+//  * split-K launches make the SPLIT the fastest-varying index, so (for 8 splits) each XCD streams one disjoint K-slab of
+//    both operands for all output tiles -- instead of every XCD re-reading the whole of B;
+//  * otherwise each XCD gets a contiguous range of tiles (xcd_remap), visited in groups of 8 tile rows x all columns taken
+//    column-by-column ("grouped" order), so the ~64 tiles resident on an XCD form an 8 x 8 patch that shares 8 A panels and
+//    8 B panels instead of 2-3 rows x 24 columns.
+struct TileCoord { int m, n, split; };
+__device__ __forceinline__ TileCoord decode_tile(int bid, int tiles_m, int tiles_n, int splits) {
+    TileCoord c;
+    int t;
+    if (splits > 1) { c.split = bid % splits; t = bid / splits; }
+    else { c.split = 0; t = xcd_remap(bid, tiles_m * tiles_n); }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = t / per_group, first_m = g * GROUP_M;
+    const int rows = min(tiles_m - first_m, GROUP_M);
+    const int r = t - g * per_group;
+    c.m = first_m + r % rows;
+    c.n = r / rows;
+    return c;
+}
 
 template <int BMN, bool KC>
 struct TileLoader {
@@ -96,9 +118,9 @@ struct TileLoader {
 
 // Epilogue shared by both main loops: lane owns column l31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*half.
 template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half, int split) {
     if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
-        float* w = g.ws + (int64_t)blockIdx.y * g.M * g.N;
+        float* w = g.ws + (int64_t)split * g.M * g.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = col0 + 32 * j + l31;
@@ -157,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
-    const int t = xcd_remap(blockIdx.x, g.ntiles);
-    const int m0 = (t / g.tiles_n) * BM, n0 = (t % g.tiles_n) * BN;
+    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits);
+    const int m0 = tc.m * BM, n0 = tc.n * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[LA::NV], rb[LB::NV];
-    const int kbeg = blockIdx.y * g.kchunk;
+    const int kbeg = tc.split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);          // loaders zero-fill past kend
     const int nk = (kend - kbeg + BK - 1) / BK;
     LA::load(ra, g.A, g.lda, g.M, kend, m0, kbeg, g.vecA, tid);
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half);
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -265,9 +287,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave >> 1) * (BM / WM), wn0 = (wave & 1) * (BN / 2);
-    const int t = xcd_remap(blockIdx.x, g.ntiles);
-    const int m0 = (t / g.tiles_n) * BM, n0 = (t % g.tiles_n) * BN;
-    const int kbeg = blockIdx.y * g.kchunk;
+    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits);
+    const int m0 = tc.m * BM, n0 = tc.n * BN;
+    const int kbeg = tc.split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg) / BK;
 
@@ -370,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
             }
         }
     }
-    gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half);
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
 }
 
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic.  One thread per 4 consecutive columns.
@@ -426,9 +448,10 @@ static int plan_splits(int M, int N, int K, int epilogue) {
 
 template <int BM, int BN>
 static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
+    g.tiles_m = (int)cdiv(g.M, BM);
     g.tiles_n = (int)cdiv(g.N, BN);
-    g.ntiles = (int)cdiv(g.M, BM) * g.tiles_n;
-    dim3 grid(g.ntiles, g.splits), block(256);
+    g.ntiles = g.tiles_m * g.tiles_n;
+    dim3 grid(g.ntiles * g.splits), block(256);
     if (g.fast) {
 #define YT_DMA(V, NW)                                                                                                                   \
     do {                                                                                                                               \
