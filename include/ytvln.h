@@ -49,11 +49,15 @@ enum {
  *   bias: [N] or NULL.  beta: 0 = overwrite, 1 = accumulate into C.  aux/ldaux: see the epilogue enum (may be NULL).
  *   workspace: optional scratch of ytvln_gemm_workspace_elems(M,N,K,epilogue) floats.  When it is supplied and the output
  *   has too few 128x128 tiles to fill 256 CUs (weight gradients: [out,in] outputs contracted over N*T or N*R rows), the
- *   contraction is split across workgroups and reduced in a fixed order (deterministic split-K); otherwise ignored. */
+ *   contraction is split across workgroups and reduced in a fixed order (deterministic split-K); otherwise ignored.
+ *   flags: YTVLN_GEMM_A_ZERO_PADDED = the caller guarantees readable ZERO padding behind A's contiguous dimension up to
+ *   lda (rounded to 32 for a K-contiguous A with B = [K,N]; to 4 for an M-contiguous A).  It lets the 30522- and 1601-wide
+ *   logit gradients (vilbert.py:906, 968 backward) use the LDS-DMA main loop although 30522 % 32 != 0. */
+#define YTVLN_GEMM_A_ZERO_PADDED 1
 int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
 int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
-                   float beta, float* workspace, int64_t workspace_elems, void* stream);
+                   float beta, float* workspace, int64_t workspace_elems, int flags, void* stream);
 
 /* out[b, n] = sum over the b-th block of `rows_per_block` rows of x[:, n].  out is [ceil(M/rows_per_block), N] with
  * leading dimension ldo (bias gradients, position-embedding gradient, second stage of every column reduction). */

@@ -62,7 +62,7 @@ def test_every_declared_symbol_is_exported_and_bound_with_the_declared_signature
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
     from ytvln import _lib
     lib = _lib.load()
-    rc = lib.ytvln_gemm_f32(None, 1, 0, None, 1, 0, None, 1, None, None, 0, 4, 4, 4, 0, 0.0, None, 0, None)
+    rc = lib.ytvln_gemm_f32(None, 1, 0, None, 1, 0, None, 1, None, None, 0, 4, 4, 4, 0, 0.0, None, 0, 0, None)
     assert rc != 0 and b"null" in lib.ytvln_last_error()
     with pytest.raises(RuntimeError, match="ytvln_ln_fwd_f32 failed"):
         _lib.call("ytvln_ln_fwd_f32", 16, None, 16, 16, 16, None, None, None, 4, 30, 1e-12, 0.0, 0.0, None, 0, None)   # H % 4 != 0

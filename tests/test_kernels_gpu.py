@@ -499,3 +499,33 @@ def test_adamw_kernel_matches_reference_kat(dev, lib):
     close(opt.state[p]["exp_avg"], k["adamw/m"], 1e-8, 2e-6, "exp_avg")
     close(opt.state[p]["exp_avg_sq"], k["adamw/v"], 1e-9, 2e-5, "exp_avg_sq")
     assert opt.state[p]["step"] == 3
+
+
+def test_gemm_zero_padded_tails(dev, lib):
+    """Fast-path GEMM with a zero-padded K tail (K % 32 != 0, B rows clamped) and an M tail (M % 4 != 0) -- the shapes of
+    the 30522-wide logit gradient (dX = dlogits . E, dE = dlogits^T . h)."""
+    from ytvln import ops
+    from ytvln._lib import GEMM_A_ZERO_PADDED
+    M, V, H = 300, 1001 + 32 * 3 + 5, 96         # V = 1102: not a multiple of 4 or 32
+    ld = (V + 31) // 32 * 32
+    dl = torch.zeros(M, ld, device=dev)
+    dl[:, :V] = rnd(dev, M, V, seed=1)
+    E, h = rnd(dev, V, H, seed=2), rnd(dev, M, H, seed=3)
+    dx = torch.empty(M, H, device=dev)
+    ops._gemm(dl, ld, 0, E, H, 0, dx, H, M, H, V, flags=GEMM_A_ZERO_PADDED)          # K = V with a tail
+    close(dx, dl[:, :V].double() @ E.double(), 1e-3, 1e-4, "dX with K tail")
+    dE = torch.empty(V, H, device=dev)
+    ops._gemm(dl, ld, 1, h, H, 0, dE, H, V, H, M, flags=GEMM_A_ZERO_PADDED)          # M = V with a tail
+    close(dE, dl[:, :V].double().t() @ h.double(), 1e-3, 1e-4, "dW with M tail")
+    # the same through autograd: linear -> cross-entropy with a wide odd vocabulary keeps the padded leading dimension
+    x = rnd(dev, M, H, seed=4).requires_grad_(True)
+    W = (rnd(dev, 1601, H, seed=5) * 0.1).requires_grad_(True)
+    b = rnd(dev, 1601, seed=6).requires_grad_(True)
+    t = torch.randint(0, 1601, (M,), generator=torch.Generator().manual_seed(1)).to(dev)
+    logits = ops.linear(x, W, b)
+    assert logits.shape == (M, 1601) and logits.stride(0) == 1632
+    ops.cross_entropy(logits, t, -1).backward()
+    xd, Wd, bd = (v.detach().double().requires_grad_(True) for v in (x, W, b))
+    F.cross_entropy(F.linear(xd, Wd, bd), t).backward()
+    for a, r, nme in ((x, xd, "x"), (W, Wd, "W"), (b, bd, "b")):
+        assert rel_l2(a.grad, r.grad) < 2e-5, nme

@@ -28,6 +28,9 @@ struct GemmArgs {
     int splits, kchunk;   // split-K: blockIdx.y owns k in [y*kchunk, (y+1)*kchunk); partial tiles go to ws[y][M][N]
     float* ws;
     int fast;             // LDS-DMA main loop legal (K % 32 == 0, aligned operands, M/N-contiguous extents % 4 == 0)
+    int Kloop;            // contraction length the fast kernel iterates over (K rounded up to 32 when A's K tail is zero-padded)
+    int mnA, mnB;         // clamp extents of the operands in their M / N dimension (rounded up to 4 inside padding)
+    int ktail;            // 1: the last k-tile reaches past K -> M/N-contiguous operands clamp their k rows to K-1
 };
 
 constexpr int BK = 32;
@@ -248,7 +251,11 @@ template <int BMN, bool KC, int NW>
 struct DmaTile {
     static constexpr int NI = BMN / 8 / NW;        // 1 KiB pieces per wave per tile (BMN/8 pieces, NW waves)
     // per-lane source pointer of piece i for the tile starting at k0 (advanced by the caller)
-    __device__ static __forceinline__ const float* src(const float* P, int64_t ld, int MN, int mn0, int k0, int wave, int lane, int i) {
+    // MN: extent used for clamping rows (K-contiguous operand) / 16-byte column granules (M/N-contiguous operand);
+    // kmax: last valid k row of an M/N-contiguous operand (rows past it are clamped: they meet zero padding of the other
+    // operand's K tail, see YTVLN_GEMM_A_ZERO_PADDED).
+    __device__ static __forceinline__ const float* src(const float* P, int64_t ld, int MN, int mn0, int k0, int wave, int lane, int i,
+                                                       int kmax) {
         const int c = wave * NI + i;
         if (KC) {
             const int m = c * 8 + (lane >> 3);
@@ -259,7 +266,7 @@ struct DmaTile {
             const int per_row = BMN / 4;                       // float4 per k-row
             const int k = (c * 64 + lane) / per_row, mn = ((c * 64 + lane) % per_row) * 4;
             const int col = min(mn0 + mn, MN - 4);
-            return P + (int64_t)(k0 + k) * ld + col;
+            return P + (int64_t)min(k0 + k, kmax) * ld + col;
         }
     }
     __device__ static __forceinline__ int64_t step(int64_t ld) { return KC ? 32 : 32 * ld; }   // floats per k-tile
@@ -290,15 +297,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
     const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits);
     const int m0 = tc.m * BM, n0 = tc.n * BN;
     const int kbeg = tc.split * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
+    const int kend = min(g.Kloop, kbeg + g.kchunk);
     const int nk = (kend - kbeg) / BK;
+    const bool tail_here = g.ktail && kend == g.Kloop;       // this workgroup's last k-tile crosses K
 
     const float* pa[TA::NI];
     const float* pb[TB::NI];
 #pragma unroll
-    for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.M, m0, kbeg, wave, lane, i);
+    for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg, wave, lane, i, 0x7fffffff);
 #pragma unroll
-    for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.N, n0, kbeg, wave, lane, i);
+    for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg, wave, lane, i, 0x7fffffff);
     const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
 
     f32x16 acc[TM][TN];
@@ -309,9 +317,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto issue = [&](int stage) {
-        float* As = smem + stage * STAGE;
+    auto issue = [&](int kt) {
+        float* As = smem + (kt & 1) * STAGE;
         float* Bs = As + SA;
+        if (tail_here && kt == nk - 1) {      // rare: K tail -- recompute the sources with clamped k rows
+#pragma unroll
+            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * BK, wave, lane, i, g.K - 1);
+#pragma unroll
+            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * BK, wave, lane, i, g.K - 1);
+        }
 #pragma unroll
         for (int i = 0; i < TA::NI; ++i) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
         // my pieces of tile kt have landed; after the barrier everybody's have, and everybody is done reading the other stage
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue((kt + 1) & 1);
+        if (kt + 1 < nk) issue(kt + 1);
         const float* As = smem + (kt & 1) * STAGE;
         const float* Bs = As + SA;
         if (VAR & 1) {      // fragments of k-group sg+1 are fetched while the MFMAs of group sg run
@@ -500,7 +514,7 @@ extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue)
 
 extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                               int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
-                              int epilogue, float beta, float* workspace, int64_t workspace_elems, void* stream) {
+                              int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, void* stream) {
     YT_REQUIRE(A && B && C, "gemm: null operand");
     YT_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
     YT_REQUIRE(epilogue >= YTVLN_EPI_NONE && epilogue <= YTVLN_EPI_MUL_DRELU, "gemm: bad epilogue %d", epilogue);
@@ -515,14 +529,25 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     hipStream_t s = as_stream(stream);
     g.splits = 1; g.kchunk = K; g.ws = nullptr;
-    g.fast = (K > 0) && (K % BK == 0) && g.vecA && g.vecB && (transA ? (M % 4 == 0 && M >= 4) : true) &&
-             (!transB ? (N % 4 == 0 && N >= 4) : true) && !getenv("YTVLN_GEMM_GENERIC");
+    // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
+    // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
+    // B's k rows are clamped -- B must be [K,N]), and an M-contiguous A may have M % 4 != 0.
+    const bool apad = (flags & YTVLN_GEMM_A_ZERO_PADDED) != 0;
+    const int k32 = (int)cdiv(K, BK) * BK, m4 = (int)cdiv(M, 4) * 4;
+    g.Kloop = K; g.ktail = 0; g.mnA = M; g.mnB = N;
+    bool k_ok = (K % BK == 0);
+    if (!k_ok && apad && !transA && !transB && lda >= k32) { k_ok = true; g.Kloop = k32; g.ktail = 1; }
+    bool ma_ok = !transA || (M % 4 == 0 && M >= 4);
+    if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
+    g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
+             !getenv("YTVLN_GEMM_GENERIC");
     const int want = plan_splits(M, N, K, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
         g.splits = (int)cdiv(K, g.kchunk);
         g.ws = workspace;
     }
+    if (g.splits == 1) g.kchunk = std::max(g.kchunk, g.Kloop);
     if (g.splits > 1) {
         launch_tile<128, 128>(g, transA, transB, s);
         const int64_t total = (int64_t)M * N;

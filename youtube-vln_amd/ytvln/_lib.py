@@ -24,7 +24,7 @@ P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 # name -> argtypes, exactly mirroring include/ytvln.h (tests/test_abi.py checks header <-> table <-> exported symbols)
 SIGNATURES = {
     "ytvln_gemm_workspace_elems": [I32, I32, I32, I32],
-    "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, P],
+    "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P],
     "ytvln_colsum_f32": [P, I64, I32, I32, P, I64, I32, P],
     "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
     "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],
@@ -49,6 +49,7 @@ SIGNATURES = {
 }
 
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
+GEMM_A_ZERO_PADDED = 1
 ABI_VERSION = 1
 
 _lib = None

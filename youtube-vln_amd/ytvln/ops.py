@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import EPI_GELU, EPI_MUL_DGELU, EPI_NONE, EPI_RELU, call
+from ._lib import EPI_GELU, EPI_MUL_DGELU, EPI_NONE, EPI_RELU, GEMM_A_ZERO_PADDED, call
 
 Tensor = torch.Tensor
 _ACT = {"none": EPI_NONE, None: EPI_NONE, "gelu": EPI_GELU, "relu": EPI_RELU}
@@ -91,14 +91,14 @@ class DropoutState:
 _WS_CACHE = {}
 
 
-def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0):
+def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0):
     key = (M, N, K, epi)
     need = _WS_CACHE.get(key)
     if need is None:
         need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, K, epi))
     ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
     call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
-         M, N, K, epi, float(beta), _ptr(ws), need, _stream())
+         M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _stream())
 
 
 def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> Tensor:
@@ -223,6 +223,56 @@ def pack_rows(*params):
     return w
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# wide, oddly sized outputs (30522-way language logits, 1601-way vision logits) live in buffers whose leading dimension is
+# rounded up to 32 floats: rows stay 16-byte aligned and their gradients can feed the LDS-DMA GEMM (zero-padded K tail).
+# ------------------------------------------------------------------------------------------------------------------
+import weakref as _weakref
+
+_ZERO_PADDED = {}       # storage data_ptr -> leading dimension, for gradient buffers whose pad columns are known to be zero
+
+
+def _pad_ld(n: int) -> int:
+    return (n + 31) // 32 * 32 if (n >= 1024 and n % 32) else n
+
+
+def _alloc_rows(M: int, N: int, device, zero_pad: bool = False):
+    """[M, N] fp32 view with leading dimension _pad_ld(N); with zero_pad the pad columns are cleared and remembered."""
+    ld = _pad_ld(N)
+    if ld == N:
+        return torch.empty((M, N), dtype=torch.float32, device=device), N
+    full = torch.empty((M, ld), dtype=torch.float32, device=device)
+    if zero_pad:
+        full[:, N:].zero_()
+        key = full.untyped_storage().data_ptr()
+        _ZERO_PADDED[key] = ld
+        _weakref.finalize(full, _ZERO_PADDED.pop, key, None)      # `full` stays alive as the base of the returned view
+    return full[:, :N], ld
+
+
+def _view_rows_as(rows: Tensor, ld: int, shape):
+    """View a [M, N] row buffer with leading dimension ld as `shape` (= (*lead, N))."""
+    shape = tuple(shape)
+    if ld == shape[-1]:
+        return rows.view(shape)
+    strides, acc = [], ld
+    for dim in reversed(shape[:-1]):
+        strides.append(acc)
+        acc *= dim
+    return torch.as_strided(rows, shape, tuple(reversed(strides)) + (1,))
+
+
+def _rows_of_grad(dy: Tensor, M: int, N: int):
+    """(dy as [M, N] rows, leading dimension, GEMM flags): keeps a padded-leading-dimension gradient in place."""
+    d2 = dy.reshape(M, N)
+    if d2.stride(1) == 1 and d2.stride(0) > N and d2.stride(0) % 4 == 0 and d2.data_ptr() % 16 == 0:
+        known = _ZERO_PADDED.get(d2.untyped_storage().data_ptr()) == d2.stride(0) and d2.storage_offset() == 0
+        return d2, d2.stride(0), (GEMM_A_ZERO_PADDED if known else 0), known
+    if not d2.is_contiguous():
+        d2 = d2.contiguous()
+    return d2, N, 0, False
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b)  -- nn.Linear + optional erf-GELU / ReLU epilogue, all on the fp32 MFMA GEMM."""
 
@@ -236,16 +286,19 @@ class LinearFn(torch.autograd.Function):
         N = weight.shape[0]
         assert weight.shape[1] == K, (weight.shape, K)
         need_grad = any(ctx.needs_input_grad)
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         epi = _ACT[act]
+        if epi == EPI_NONE:
+            y, ldy = _alloc_rows(M, N, x.device)          # wide odd widths (logits) get a 32-float aligned leading dimension
+        else:
+            y, ldy = torch.empty((M, N), dtype=torch.float32, device=x.device), N
         z = torch.empty_like(y) if (epi == EPI_GELU and need_grad) else None
-        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, N, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
+        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
         ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
         ctx.in_shape = x.shape
         ctx.targets = _targets_of(weight)
         ctx.btargets = _targets_of(bias) if bias is not None else None
         ctx.save_for_backward(x2, weight, z if epi == EPI_GELU else (y if epi == EPI_RELU else None))
-        return y.view(*x.shape[:-1], N)
+        return _view_rows_as(y, ldy, tuple(x.shape[:-1]) + (N,))
 
     @staticmethod
     def backward(ctx, dy):
@@ -253,25 +306,27 @@ class LinearFn(torch.autograd.Function):
             return None, None, None, None
         x2, weight, aux = ctx.saved_tensors
         M, N, K = ctx.dims
-        dy = dy.reshape(M, N)
-        if not dy.is_contiguous():
-            dy = dy.contiguous()
         if ctx.epi != EPI_NONE:
+            dy = dy.reshape(M, N)
+            if not dy.is_contiguous():
+                dy = dy.contiguous()
             dz = torch.empty_like(dy)
             call("ytvln_act_bwd_f32", _ptr(dy), _ptr(aux), _ptr(dz), dy.numel(), ctx.epi, _stream())
-            dy = dz
+            dy, ldy, flags = dz, N, 0
+        else:
+            dy, ldy, flags, _ = _rows_of_grad(dy, M, N)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, N, 0, weight, weight.stride(0), 0, dx, K, M, K, N)
+            _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags)
             dx = dx.view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
             dw = _direct_grad(ctx.targets, (N, K))
             if dw is None:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, N, 1, x2, ctx.lda, 0, dw, K, N, K, M)
+            _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, M, N, N, out=_direct_grad(ctx.btargets, (N,)))
+            db = colsum(dy, M, N, ldy, out=_direct_grad(ctx.btargets, (N,)))
         return dx, dw, db, None
 
 
@@ -659,9 +714,9 @@ class CrossEntropyFn(torch.autograd.Function):
         lg, tg, row_lse, out = ctx.saved_tensors
         M, V, ld, ign, shape = ctx.meta
         g = g.reshape(1).contiguous().float()
-        dl = torch.empty((M, V), dtype=torch.float32, device=lg.device)
-        call("ytvln_ce_bwd_f32", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dl), V, M, V, _stream())
-        return dl.view(shape), None, None
+        dl, ldd = _alloc_rows(M, V, lg.device, zero_pad=True)
+        call("ytvln_ce_bwd_f32", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dl), ldd, M, V, _stream())
+        return _view_rows_as(dl, ldd, shape), None, None
 
 
 def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:
@@ -694,9 +749,9 @@ class KLMaskedFn(torch.autograd.Function):
         pr, tg, mk, row_lse, out = ctx.saved_tensors
         M, Cc, ld, ldt, shape = ctx.meta
         g = g.reshape(1).contiguous().float()
-        dp = torch.empty((M, Cc), dtype=torch.float32, device=pr.device)
-        call("ytvln_kl_bwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dp), Cc, M, Cc, _stream())
-        return dp.view(shape), None, None
+        dp, ldd = _alloc_rows(M, Cc, pr.device, zero_pad=True)
+        call("ytvln_kl_bwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dp), ldd, M, Cc, _stream())
+        return _view_rows_as(dp, ldd, shape), None, None
 
 
 def kl_masked(pred: Tensor, target: Tensor, mask: Tensor) -> Tensor:
