@@ -39,6 +39,8 @@ WORKLOADS = {
     # name: (config json, bs, K, T, frames, boxes, flags)
     "cfg2_full_pretrain_bs8": ("bert_base_6_layer_6_connect.json", 8, 7, 80, 8, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
     "cfg1_tiny_mlm_bs2": ("tiny_2_2_1.json", 2, 7, 16, 1, 8, dict(masked_language=True)),
+    # BASELINE configs[3]: train.py --ranking --shuffle_visual_features, 4 beams + 2 negatives, 7 steps x 36 regions, bs=16/GPU
+    "cfg4_finetune_rank_bs16": ("bert_base_6_layer_6_connect.json", 16, 6, 80, 7, 36, dict(ranking=True, pretrain=False)),
 }
 
 
@@ -191,7 +193,8 @@ def main():
         for m in model.modules():
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
-    batch = synth.to_torch(synth.make_batch(bs=bs, K=K, T=T, frames=frames, boxes=boxes, seed=1234 + rank), dev)
+    batch = synth.to_torch(synth.make_batch(bs=bs, K=K, T=T, frames=frames, boxes=boxes, seed=1234 + rank,
+                                            finetune_heading=not args.pretrain), dev)
     runner = model
     if world > 1:
         runner = DataParallel(model, broadcast=True)
