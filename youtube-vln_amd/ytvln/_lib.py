@@ -82,12 +82,19 @@ def load():
     if lib.ytvln_version() != ABI_VERSION:
         raise YtvlnLibraryError(f"ABI mismatch: library {lib.ytvln_version()} != binding {ABI_VERSION}")
     _lib = lib
+    _FN.update({name: getattr(lib, name) for name in SIGNATURES})
     return lib
+
+
+_FN = {}
 
 
 def call(name: str, *args):
     """Invoke an entry point; non-zero status -> RuntimeError carrying ytvln_last_error()."""
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        load()
+        fn = _FN[name]
+    rc = fn(*args)
     if rc != 0:
-        raise RuntimeError(f"{name} failed ({rc}): {lib.ytvln_last_error().decode(errors='replace')}")
+        raise RuntimeError(f"{name} failed ({rc}): {_lib.ytvln_last_error().decode(errors='replace')}")
