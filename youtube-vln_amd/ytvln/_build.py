@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(f"[ytvln build] compiled {os.path.basename(done)}", file=sys.stderr)
     objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in sources()]
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,-z,defs", *objs, "-o", LIB]   # unresolved symbols fail the link
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
