@@ -318,3 +318,65 @@ def test_graph_replay_equals_eager(dev, lib):
     assert abs(losses[0] - losses[1]) < 1e-6, losses
     # (not bit-equal: the word-embedding gradient is an atomic scatter-add whose summation order varies run to run)
     assert float((finals[0] - finals[1]).abs().max()) < 2e-6, float((finals[0] - finals[1]).abs().max())
+
+
+def test_save_resume_and_eval_loops(dev, lib, tmp_path):
+    """save_model -> get_optimization(--resume) continues bit-for-bit like an uninterrupted run; val_epoch / test_epoch agree
+    with a direct evaluation (reference utils_init.py:277-295, 315-446, vilbert_init.py:44-70)."""
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    nb = synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0)
+    batch = synth.to_torch(nb, dev)
+
+    def fresh():
+        m, _ = build_lily(dev, "micro.json", args, seed=11)
+        m.train()
+        return m
+
+    # uninterrupted: 4 steps
+    m0 = fresh()
+    o0, s0, _, _ = get_optimization(args, m0, 10, None)
+    for i in range(4):
+        U.train_step(m0, o0, s0, batch, args, i, all_options=True)
+    # interrupted after 2 steps, saved, resumed in a new process-like state
+    m1 = fresh()
+    o1, s1, _, _ = get_optimization(args, m1, 10, None)
+    for i in range(2):
+        U.train_step(m1, o1, s1, batch, args, i, all_options=True)
+    U.save_model(str(tmp_path), "ckpt", None, m1, o1, s1, epoch=7)
+    ck = torch.load(U.get_model_path(str(tmp_path), "ckpt"), map_location="cpu")
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "epoch"}
+    st = next(iter(ck["optimizer_state_dict"]["state"].values()))
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and st["step"] == 2
+    m2 = fresh()
+    rargs = args_ns(**{**vars(args), "resume": True, "from_pretrained": U.get_model_path(str(tmp_path), "ckpt")})
+    o2, s2, _, start_epoch = get_optimization(rargs, m2, 10, None)
+    assert start_epoch == 8
+    for i in range(2, 4):
+        U.train_step(m2, o2, s2, batch, args, i, all_options=True)
+    a = torch.cat([p.detach().reshape(-1) for p in m0.parameters()])
+    b = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+    assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+    U.delete_model(str(tmp_path), "ckpt")
+    assert not (tmp_path / "ckpt.bin").exists()
+
+    # evaluation loops on a 2-batch "loader" with a multi-hot beam target
+    tgt = np.zeros((2, 3), bool); tgt[0, 0] = True; tgt[1, 1] = True
+    eb = list(nb); eb[0] = tgt
+    loader = [synth.to_torch(eb), synth.to_torch(eb)]
+    sr = U.val_epoch(0, m0, "val_seen", loader, None, True, args, 0, None, "ranking")
+    red = U.test_epoch(0, m0, "test", loader, None, True, args, 0, None)
+    m0.eval()
+    with torch.no_grad():
+        out = m0(*U.get_model_input(synth.to_torch(eb, dev), True))
+    logit = out["ranking"].view(2, 3).double()
+    t = torch.from_numpy(tgt).to(dev)
+    import torch.nn.functional as F
+    ref_loss = F.binary_cross_entropy_with_logits(logit, t.double())
+    ref_sr = t.gather(1, logit.argmax(1, keepdim=True)).double().sum() / 2
+    assert abs(float(sr) - float(ref_sr)) < 1e-6
+    assert abs(float(red["ranking"][1]) - float(ref_loss)) < 1e-5 and abs(float(red["ranking"][2]) - float(ref_sr)) < 1e-6
+    assert set(red) == {"ranking", "traj"}

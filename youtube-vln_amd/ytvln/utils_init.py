@@ -180,3 +180,106 @@ def train_epoch(epoch, model, optimizer, scheduler, data_loader, writer, default
                 writer.add_scalar(f"accuracy/{task}", float(item), global_step=global_step)
             for task, item in reduced_metrics["loss"].items():
                 writer.add_scalar(f"loss/{task}", float(item), global_step=global_step)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# checkpoints and evaluation loops (reference utils/utils_init.py:273-446)
+# ------------------------------------------------------------------------------------------------------------------
+import os
+
+from torch import nn
+
+
+def get_model_path(model_save_path, save_name):
+    return os.path.join(model_save_path, f"{save_name}.bin")
+
+
+def save_model(model_save_path, save_name, logger, model, optimizer, scheduler, epoch):
+    """utils_init.py:277-295: `{model_state_dict, optimizer_state_dict, scheduler_state_dict, epoch}` in one `.bin`.
+    The state-dict keys and the per-parameter optimizer state (`step`, `exp_avg`, `exp_avg_sq`) are the reference's, so the
+    file resumes in either implementation (tensors are cloned out of the flat arenas so the file stays self-contained)."""
+    net = model.module if hasattr(model, "module") and isinstance(model.module, nn.Module) else model
+    if not isinstance(net, nn.Module):
+        raise ValueError("Can't find the Module here")
+    if logger:
+        logger.info(f"saving the {save_name} model")
+    opt_state = optimizer.state_dict()
+    for st in opt_state["state"].values():
+        for k, v in list(st.items()):
+            if torch.is_tensor(v):
+                st[k] = v.detach().clone()
+    torch.save({"model_state_dict": {k: v.detach().clone() for k, v in net.state_dict().items()},
+                "optimizer_state_dict": opt_state, "scheduler_state_dict": scheduler.state_dict(), "epoch": epoch},
+               get_model_path(model_save_path, save_name))
+
+
+def delete_model(model_save_path, save_name):
+    model_path = get_model_path(model_save_path, save_name)
+    if os.path.exists(model_path):
+        os.unlink(model_path)
+
+
+def _to_device(batch, device):
+    return tuple(t.to(device, non_blocking=True) if hasattr(t, "to") else t for t in batch)
+
+
+def test_epoch(epoch: int, model, tag, data_loader, writer, default_gpu, args, global_step, logger):
+    """utils_init.py:315-379: eval-mode ranking / traj losses and success rates, accumulated on the device."""
+    device = next(model.parameters()).device
+    model.eval()
+    stats = {}
+    if args.ranking:
+        stats["ranking"] = torch.zeros(4, device=device)
+    if args.traj_judge:
+        stats["traj"] = torch.zeros(4, device=device)
+    with torch.no_grad():
+        for batch in data_loader:
+            all_options = bool(batch[13].all()) if not batch[13].is_cuda else None
+            batch = _to_device(batch, device)
+            outputs = model(*get_model_input(batch, all_options))
+            for task in stats:
+                batch_size, _, loss, correct = get_loss_correct(batch, outputs, task, args, logger, False, bool(all_options))
+                stats[task] += torch.stack([torch.full((), float(batch_size), device=device), loss.float(), correct.float(),
+                                            torch.ones((), device=device)])
+    reduced = {task: v.clone() for task, v in stats.items()}
+    if getattr(args, "local_rank", -1) != -1 and not getattr(args, "skip_all_reduce", False) and dist.is_initialized():
+        world = float(dist.get_world_size())
+        for task in reduced:
+            dist.all_reduce(reduced[task], op=dist.ReduceOp.SUM)
+            reduced[task][1] /= world
+    for task in reduced:
+        reduced[task][1] /= reduced[task][3]
+        reduced[task][2] /= reduced[task][0]
+    if default_gpu and writer is not None:
+        for task, item in reduced.items():
+            writer.add_scalar(f"loss/{task}_{tag}", float(item[1]), global_step=global_step)
+            writer.add_scalar(f"accuracy/{task}_{tag}", float(item[2]), global_step=global_step)
+    return reduced
+
+
+def val_epoch(epoch: int, model, tag, data_loader, writer, default_gpu, args, global_step, logger, task):
+    """utils_init.py:382-446: beam re-ranking validation -- BCE-with-logits against the multi-hot target and the success
+    rate of the top-scoring beam."""
+    device = next(model.parameters()).device
+    model.eval()
+    stats = torch.zeros(3, device=device)
+    steps = 0
+    with torch.no_grad():
+        for batch in data_loader:
+            all_options = bool(batch[13].all()) if not batch[13].is_cuda else None
+            batch = _to_device(batch, device)
+            outputs = model(*get_model_input(batch, all_options))
+            opt_mask = get_mask_options(batch)
+            target = get_ranking_target(batch)
+            logit = outputs[task].squeeze(1).view(opt_mask.shape) if all_options else pad_packed(outputs[task].squeeze(1), opt_mask)
+            loss = ops.bce_with_logits(logit, target.float())
+            correct = torch.sum(target.gather(1, torch.argmax(logit, 1).view(-1, 1))).float()
+            stats += torch.stack([torch.full((), float(get_batch_size(batch)), device=device), loss.float(), correct])
+            steps += 1
+    if getattr(args, "local_rank", -1) != -1 and dist.is_initialized():
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    success_rate = stats[2] / stats[0]
+    if default_gpu and writer is not None:
+        writer.add_scalar(f"loss/{task}_{tag}", float(stats[1] / max(steps, 1)), global_step=global_step)
+        writer.add_scalar(f"accuracy/{task}_{tag}", float(success_rate), global_step=global_step)
+    return success_rate
