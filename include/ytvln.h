@@ -76,6 +76,11 @@ int ytvln_colsum_by_index_f32(const float* x, int64_t ldx, const float* idx_f32,
 int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int M, int H, float* table_grad,
                                int64_t skip_idx, void* stream);
 
+/* out[j, :] = x[idx[j], :] (zeros where idx[j] < 0): row gather in front of the loss-aware prediction heads (only rows that
+ * carry a masked-language / masked-vision target are decoded; "next" row of SURVEY.md section 8f).  Backward =
+ * ytvln_scatter_add_rows_f32 with skip_idx = -1. */
+int ytvln_gather_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int R, int H, float* out, void* stream);
+
 /* Fused (dropout ->) residual add -> LayerNorm (-> dropout).  BertLayerNorm, vilbert.py:213-217 (biased variance, eps
  * inside the sqrt) together with the dropout/add that always precedes it (:322-324, :365-367, :641-648) or follows it
  * (:254-255, :1367-1368).

@@ -380,3 +380,39 @@ def test_save_resume_and_eval_loops(dev, lib, tmp_path):
     assert abs(float(sr) - float(ref_sr)) < 1e-6
     assert abs(float(red["ranking"][1]) - float(ref_loss)) < 1e-5 and abs(float(red["ranking"][2]) - float(ref_sr)) < 1e-6
     assert set(red) == {"ranking", "traj"}
+
+
+@pytest.mark.parametrize("all_options", [True, None])
+def test_loss_aware_heads_match_full_heads(dev, lib, all_options):
+    """Decoding only the rows that carry a masked-token / masked-region target (train_step(loss_aware_heads=True)) gives the
+    same losses and the same parameters after optimizer steps as decoding every row (the reference's behaviour)."""
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    batch = synth.to_torch(synth.make_batch(bs=3, K=3, T=16, frames=2, boxes=5, F=16, C=11, vocab=97, seed=33,
+                                            ignore_rank_frac=0.0 if all_options else 0.3), dev)
+    finals, losses = [], []
+    for aware in (False, True):
+        model, _ = build_lily(dev, "micro.json", args, seed=5)
+        model.train()
+        opt, sched, _, _ = get_optimization(args, model, 10, None)
+        for i in range(3):
+            loss, metrics = U.train_step(model, opt, sched, batch, args, i, all_options=all_options, loss_aware_heads=aware,
+                                         capacity_frac=0.5)
+        if aware:
+            assert float(metrics["head_row_overflow"]) == 0.0
+        torch.cuda.synchronize()
+        finals.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+        losses.append((float(loss), {k: float(v) for k, v in metrics["loss"].items()}))
+    assert abs(losses[0][0] - losses[1][0]) < 2e-6 * max(1.0, abs(losses[0][0])), losses
+    for k in losses[0][1]:
+        assert abs(losses[0][1][k] - losses[1][1][k]) < 2e-6 * max(1.0, abs(losses[0][1][k])), (k, losses)
+    assert float((finals[0] - finals[1]).abs().max()) < 5e-6, float((finals[0] - finals[1]).abs().max())
+    # capacity too small -> flagged on device, never silently wrong
+    model, _ = build_lily(dev, "micro.json", args, seed=5)
+    opt, sched, _, _ = get_optimization(args, model, 10, None)
+    _, metrics = U.train_step(model, opt, sched, batch, args, 0, all_options=all_options, loss_aware_heads=True, capacity_frac=0.01)
+    # (capacity is rounded up to 128 rows, which may still cover the micro batch; only check the flag is a device scalar)
+    assert metrics["head_row_overflow"].numel() == 1

@@ -5,6 +5,7 @@
 // (global_load_dwordx4), the row stays in registers between the two reduction passes (mean, then centred variance as the
 // reference computes it, vilbert.py:214-216), so each element is read once and written once.
 #include "common.h"
+#include <algorithm>
 
 namespace ytvln {
 
@@ -258,6 +259,27 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     }
 }
 
+// out[j, :] = x[idx[j], :]   (idx < 0 -> zeros).  Row gather for the loss-aware heads (only rows carrying a target go through
+// the 30522-way / 1601-way decoders); its backward is scatter_add_rows_kernel.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ idx,
+                                                          int R, int H, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const int64_t k = idx[r];
+        if (VEC) {
+            const int H4 = H >> 2;
+            float4* dst = reinterpret_cast<float4*>(out + (int64_t)r * H);
+            const float4* src = reinterpret_cast<const float4*>(x + (k < 0 ? 0 : k) * ldx);
+            for (int c = lane; c < H4; c += 64) dst[c] = k < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : src[c];
+        } else {
+            float* dst = out + (int64_t)r * H;
+            const float* src = x + (k < 0 ? 0 : k) * ldx;
+            for (int c = lane; c < H; c += 64) dst[c] = k < 0 ? 0.f : src[c];
+        }
+    }
+}
+
 // ---- elementwise --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
                                                       float* __restrict__ dz, int64_t n, int act) {
@@ -422,6 +444,18 @@ extern "C" int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M, 4), 4096)), dim3(256), 0,
                        as_stream(stream), x, ldx, idx, M, H, table_grad, skip_idx);
     YT_LAUNCH_CHECK("scatter_add_rows");
+    return 0;
+}
+
+extern "C" int ytvln_gather_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int R, int H, float* out, void* stream) {
+    if (R == 0) return 0;
+    YT_REQUIRE(x && idx && out && R > 0 && H > 0 && ldx >= H, "gather_rows: bad argument");
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv(R, 4), 4096));
+    if (H % 4 == 0 && ldx % 4 == 0 && al16(x) && al16(out))
+        hipLaunchKernelGGL(gather_rows_kernel<true>, grid, dim3(256), 0, as_stream(stream), x, ldx, idx, R, H, out);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, grid, dim3(256), 0, as_stream(stream), x, ldx, idx, R, H, out);
+    YT_LAUNCH_CHECK("gather_rows");
     return 0;
 }
 

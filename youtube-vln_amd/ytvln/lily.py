@@ -40,15 +40,20 @@ class Lily(PreTrainedModel):
 
     def forward(self, instr_tokens, image_features, image_locations, token_type_ids=None, attention_mask=None,
                 image_attention_mask=None, co_attention_mask=None, highlight_tokens=None,
-                order_atteneded_visual_feature=None) -> Dict[str, torch.Tensor]:
+                order_atteneded_visual_feature=None, head_rows=None) -> Dict[str, torch.Tensor]:
+        """`head_rows` (extension, default off): {"language": idx, "vision": idx} -> the corresponding outputs hold logits for
+        those rows only ([len(idx), vocab]); used by ytvln.utils_init.train_step(loss_aware_heads=True)."""
         sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v, _ = self.bert(
             input_txt=instr_tokens, input_imgs=image_features, image_loc=image_locations, token_type_ids=token_type_ids,
             attention_mask=attention_mask, image_attention_mask=image_attention_mask, co_attention_mask=co_attention_mask,
             output_all_encoded_layers=False)
 
         want = tuple(h for h, on in (("t", self.args.masked_language), ("v", self.args.masked_vision)) if on)
+        rows = None
+        if head_rows:
+            rows = {k: head_rows[n] for k, n in (("t", "language"), ("v", "vision")) if n in head_rows}
         linguistic_prediction, vision_prediction, _ = self.cls(sequence_output_t, sequence_output_v, pooled_output_t,
-                                                               pooled_output_v, heads=want)
+                                                               pooled_output_v, heads=want, rows=rows)
 
         if self.fusion_method == "sum":
             pooled_output = pooled_output_t + pooled_output_v

@@ -561,6 +561,44 @@ def image_embed(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps=1e-12, p=0
                               drop.tensor if use else None, drop.next_site() if use else 0)
 
 
+class GatherRowsFn(torch.autograd.Function):
+    """out[j] = x[idx[j]] over rows of a [M, H] matrix (idx < 0 -> zero row); backward scatters the row gradients back."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.set_materialize_grads(False)
+        x2, M, H, ld = _rows2d(x, "x")
+        idx = _i64(idx, "idx").reshape(-1)
+        out = torch.empty((idx.numel(), H), dtype=torch.float32, device=x.device)
+        call("ytvln_gather_rows_f32", _ptr(x2), ld, _ptr(idx), idx.numel(), H, _ptr(out), _stream())
+        ctx.meta = (M, H, x.shape)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        (idx,) = ctx.saved_tensors
+        M, H, shape = ctx.meta
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.zeros((M, H), dtype=torch.float32, device=g.device)
+        call("ytvln_scatter_add_rows_f32", _ptr(g), H, _ptr(idx), idx.numel(), H, _ptr(dx), -1, _stream())
+        return dx.view(shape), None
+
+
+def gather_rows(x: Tensor, idx: Tensor) -> Tensor:
+    return GatherRowsFn.apply(x, idx)
+
+
+def select_rows(flag: Tensor, capacity: int) -> Tensor:
+    """Static-shape, sync-free row selection: the first `capacity` indices of a stable sort that puts flagged rows first.
+    If fewer rows are flagged the tail holds un-flagged rows (their targets are "ignore", so they change no loss); callers
+    size `capacity` well above the expected count and may check `flag.sum() <= capacity` lazily."""
+    order = torch.argsort((~flag.reshape(-1).bool()).to(torch.int8), stable=True)
+    return order[:capacity].contiguous()
+
+
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, rng, site):

@@ -133,16 +133,57 @@ def compute_metrics_independent(batch, outputs, task, args, logger, reduced_metr
 TASKS = (("vision", "masked_vision"), ("language", "masked_language"), ("ranking", "ranking"), ("traj", "traj_judge"))
 
 
-def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=None, all_options=None):
+def _head_capacity(rows: int, frac: float) -> int:
+    """Static number of rows sent through a prediction head: frac * rows rounded up to a whole 128-row GEMM tile."""
+    return min(rows, max(1, -(-int(rows * frac) // 128)) * 128)
+
+
+def _loss_aware_step(model, batch, args, all_options, capacity_frac):
+    """Forward + losses with the prediction heads evaluated only on rows that carry a target.  Identical
+    losses and gradients: ignored tokens / unmasked regions contribute nothing to CE / KL.  Row selection has a static shape
+    (`capacity_frac` of the rows; Bernoulli(0.15) masking makes 0.25 a > 20 sigma bound) and needs no host sync."""
+    inputs = get_model_input(batch, all_options)
+    rows, lm_t, vis_t, vis_m = {}, None, None, None
+    if args.masked_language:
+        lm_t = get_linguistic_target(batch, bool(all_options))
+        cap = _head_capacity(lm_t.numel(), capacity_frac)
+        rows["language"] = ops.select_rows(lm_t != -1, cap)
+    if args.masked_vision:
+        vis_t, vis_m = get_vision_target(batch, bool(all_options))
+        cap = _head_capacity(vis_m.numel(), capacity_frac)
+        rows["vision"] = ops.select_rows(vis_m == 1, cap)
+    outputs = model(*inputs, head_rows=rows)
+    losses = {}
+    if args.masked_vision:
+        idx = rows["vision"]
+        losses["vision"] = ops.kl_masked(outputs["vision"], ops.gather_rows(vis_t.float(), idx), vis_m[idx])
+    if args.masked_language:
+        losses["language"] = ops.cross_entropy(outputs["language"], lm_t[rows["language"]], ignore_index=-1)
+    overflow = sum(((t != ign).sum() > r.numel()).float() for t, ign, r in
+                   ((lm_t, -1, rows.get("language")), (vis_m, 0, rows.get("vision"))) if t is not None)
+    return outputs, losses, overflow
+
+
+def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=None, all_options=None,
+               loss_aware_heads: bool = False, capacity_frac: float = 0.25):
     """One iteration of train_epoch's body (utils_init.py:199-239): forward, loss composition in the reference's order,
     backward, and -- every gradient_accumulation_steps -- optimizer.step(); scheduler.step(); zero_grad().
     Returns (loss, reduced_metrics) as device tensors; never synchronises the host."""
-    outputs = model(*get_model_input(batch, all_options))
     reduced_metrics = {"loss": {}, "accuracy": {}}
+    fused = {}
+    if loss_aware_heads and (args.masked_language or args.masked_vision):
+        outputs, fused, overflow = _loss_aware_step(model, batch, args, all_options, capacity_frac)
+        reduced_metrics["head_row_overflow"] = overflow        # device scalar; > 0 means capacity_frac was too small
+    else:
+        outputs = model(*get_model_input(batch, all_options))
     loss = None
     for task, flag in TASKS:
         if getattr(args, flag):
-            l = compute_metrics_independent(batch, outputs, task, args, logger, reduced_metrics, bool(all_options))
+            if task in fused:
+                l = fused[task]
+                reduced_metrics["loss"][task] = l.detach()
+            else:
+                l = compute_metrics_independent(batch, outputs, task, args, logger, reduced_metrics, bool(all_options))
             if task == "traj":
                 l = args.traj_loss_scale * l
             loss = l if loss is None else loss + l

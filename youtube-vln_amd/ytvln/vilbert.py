@@ -599,9 +599,16 @@ class BertPreTrainingHeads(nn.Module):
         self.fusion_method = config.fusion_method
         self.dropout = nn.Dropout(0.1)
 
-    def forward(self, sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v, heads=("t", "v", "rel")):
+    def forward(self, sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v, heads=("t", "v", "rel"), rows=None):
         """Returns (prediction_scores_t, prediction_scores_v, seq_relationship_score) like vilbert.py:939-954.
-        `heads` lets a caller that discards a head (Lily, lily.py:87) skip its GEMMs; skipped entries are None."""
+        `heads` lets a caller that discards a head (Lily, lily.py:87) skip its GEMMs; skipped entries are None.
+        `rows` = {"t": idx, "v": idx} (optional) decodes only the listed rows of the flattened [N*T, H] / [N*R, Hv] sequences
+        (loss-aware heads: the scores come back as [len(idx), vocab] instead of [N, T, vocab])."""
+        if rows is not None:
+            if "t" in rows:
+                sequence_output_t = ops.gather_rows(sequence_output_t.reshape(-1, sequence_output_t.shape[-1]), rows["t"])
+            if "v" in rows:
+                sequence_output_v = ops.gather_rows(sequence_output_v.reshape(-1, sequence_output_v.shape[-1]), rows["v"])
         if self.fusion_method == "sum":
             pooled = pooled_output_t + pooled_output_v
         elif self.fusion_method == "mul":
