@@ -1,0 +1,39 @@
+"""Attention micro-benchmark at the cfg-2 shapes (N = 56 pairs per GPU = global bs 64 on 8 GPUs).  CASES=co FWD_ONLY=1 isolates the
+BertBiAttention forward (fused QK^T -> softmax -> dropout -> PV kernel) for the north-star MFMA-utilisation counter run
+(tools/coattn_pmc.sh)."""
+import os, sys, math
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd"))
+import torch
+from ytvln import ops
+dev = torch.device("cuda", 0)
+N = 56
+cases = [("img self", 8, 128, 288, 288), ("co t->v", 8, 128, 80, 288), ("co v->t", 8, 128, 288, 80), ("txt self", 12, 64, 80, 80)]
+only = os.environ.get("CASES")          # e.g. CASES="co" -> only the BertBiAttention shapes
+if only:
+    cases = [c for c in cases if c[0].startswith(only)]
+fwd_only = bool(os.environ.get("FWD_ONLY"))
+p = float(os.environ.get("PDROP", "0.1"))
+st = ops.DropoutState(dev)
+for name, h, d, Tq, Tk in cases:
+    H = h * d
+    q, k, v = (torch.randn(N * T, H, device=dev) for T in (Tq, Tk, Tk))
+    mask = torch.zeros(N, Tk, device=dev)
+    out, dout = torch.empty(N * Tq, H, device=dev), torch.randn(N * Tq, H, device=dev)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    sc = 1 / math.sqrt(d)
+    def fwd(): return ops._attn_fwd(q, 0, H, k, 0, H, v, 0, H, mask, out, N, h, Tq, Tk, d, sc, p, st.tensor, 3)
+    lse = fwd()
+    def bwd(): ops._attn_bwd(q, 0, H, k, 0, H, v, 0, H, mask, out, dout, lse, dq, 0, H, dk, 0, H, dv, 0, H, N, h, Tq, Tk, d, sc, p, st.tensor, 3)
+    res = []
+    for f, mult in (((fwd, 4.0),) if fwd_only else ((fwd, 4.0), (bwd, 14.0))):   # fwd 2 matmuls, bwd 7 (incl. recompute) -> 2*Tq*Tk*d each
+        for _ in range(3): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res.append((ms, mult * N * h * Tq * Tk * d / ms / 1e9))
+    line = f"{name:9s} fwd {res[0][0]*1000:7.1f} us {res[0][1]:6.1f} TF/s"
+    if not fwd_only:
+        line += f" | bwd {res[1][0]*1000:7.1f} us {res[1][1]:6.1f} TF/s"
+    print(line + " (algorithmic flops 4*N*h*Tq*Tk*d fwd, 14*... bwd)", flush=True)

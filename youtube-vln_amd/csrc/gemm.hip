@@ -120,52 +120,93 @@ struct TileLoader {
 };
 
 // Epilogue shared by both main loops: lane owns column l31 of each 32x32 tile, rows (r&3) + 8*(r>>2) + 4*half.
+// The epilogue kind and the "tile lies inside the matrix" test are resolved ONCE per wave (uniform branches around fully
+// specialised store loops): the per-element switch / bounds tests of a generic loop cost more than the stores themselves.
+template <int TM, int TN, int EPI, bool INTERIOR>
+__device__ __forceinline__ void epilogue_body(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half) {
+    const bool has_beta = g.beta != 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + 32 * j + l31;
+        if (!INTERIOR && col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = row0 + 32 * i + 4 * half;
+            float* cp0 = g.C + (int64_t)rbase * g.ldc + col;
+            float* xp0 = (EPI != YTVLN_EPI_NONE && EPI != YTVLN_EPI_RELU) ? g.aux + (int64_t)rbase * g.ldaux + col : nullptr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {          // 4 rows (dr = 8q + 0..3) at a time: loads in flight together, few live registers
+                float ax[4], old[4];
+                if (EPI == YTVLN_EPI_MUL_DGELU || EPI == YTVLN_EPI_MUL_DRELU) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ax[u] = (INTERIOR || rbase + 8 * q + u < g.M) ? xp0[(int64_t)(8 * q + u) * g.ldaux] : 0.f;
+                }
+                if (has_beta) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) old[u] = (INTERIOR || rbase + 8 * q + u < g.M) ? cp0[(int64_t)(8 * q + u) * g.ldc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int dr = 8 * q + u;
+                    if (!INTERIOR && rbase + dr >= g.M) continue;
+                    float v = acc[i][j][4 * q + u] + bv;
+                    if (EPI == YTVLN_EPI_GELU) {
+                        if (g.aux) xp0[(int64_t)dr * g.ldaux] = v;
+                        v = gelu_erf(v);
+                    } else if (EPI == YTVLN_EPI_RELU) {
+                        v = fmaxf(v, 0.f);
+                    } else if (EPI == YTVLN_EPI_MUL_DGELU) {
+                        v *= dgelu_erf(ax[u]);
+                    } else if (EPI == YTVLN_EPI_MUL_DRELU) {
+                        v = ax[u] > 0.f ? v : 0.f;
+                    }
+                    if (has_beta) v += g.beta * old[u];
+                    cp0[(int64_t)dr * g.ldc] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half, int split) {
+    const bool interior = row0 + 32 * TM <= g.M && col0 + 32 * TN <= g.N;
     if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
         float* w = g.ws + (int64_t)split * g.M * g.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = col0 + 32 * j + l31;
-            if (col >= g.N) continue;
+            if (!interior && col >= g.N) continue;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = row0 + 32 * i + 4 * half;
+                float* wp = w + (int64_t)rbase * g.N + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < g.M) w[(int64_t)row * g.N + col] = acc[i][j][r];
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (interior || rbase + dr < g.M) wp[(int64_t)dr * g.N] = acc[i][j][r];
                 }
+            }
         }
         return;
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + 32 * j + l31;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                float* cp = g.C + (int64_t)row * g.ldc + col;
-                switch (g.epilogue) {
-                    case YTVLN_EPI_GELU:
-                        if (g.aux) g.aux[(int64_t)row * g.ldaux + col] = v;
-                        v = gelu_erf(v);
-                        break;
-                    case YTVLN_EPI_RELU: v = fmaxf(v, 0.f); break;
-                    case YTVLN_EPI_MUL_DGELU: v *= dgelu_erf(g.aux[(int64_t)row * g.ldaux + col]); break;
-                    case YTVLN_EPI_MUL_DRELU: v = g.aux[(int64_t)row * g.ldaux + col] > 0.f ? v : 0.f; break;
-                    default: break;
-                }
-                if (g.beta != 0.f) v += g.beta * *cp;
-                *cp = v;
-            }
-        }
+#define YT_EPI(E)                                                                        \
+    case E:                                                                              \
+        if (interior) epilogue_body<TM, TN, E, true>(g, acc, row0, col0, l31, half);     \
+        else epilogue_body<TM, TN, E, false>(g, acc, row0, col0, l31, half);             \
+        break;
+    switch (g.epilogue) {
+        YT_EPI(YTVLN_EPI_GELU)
+        YT_EPI(YTVLN_EPI_RELU)
+        YT_EPI(YTVLN_EPI_MUL_DGELU)
+        YT_EPI(YTVLN_EPI_MUL_DRELU)
+        default:
+            if (interior) epilogue_body<TM, TN, YTVLN_EPI_NONE, true>(g, acc, row0, col0, l31, half);
+            else epilogue_body<TM, TN, YTVLN_EPI_NONE, false>(g, acc, row0, col0, l31, half);
+            break;
     }
+#undef YT_EPI
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC>
@@ -239,17 +280,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 // branch-free addressing (out-of-range rows / columns are CLAMPED to valid ones; their products land in accumulator
 // rows / columns the epilogue never stores), one barrier per k-tile with the next tile's DMA in flight under the MFMAs.
 // LDS images (the DMA writes lane-linear 1 KiB pieces, so the layout is chosen through the per-lane SOURCE address):
-//   K-contiguous operand  : S[m][32]   16-byte granule g of row m stored at position g ^ (m & 7)  -> ds_read_b128 of
-//                           4 consecutive k for a fixed m is (at most 2-way) conflict-free;
+//   K-contiguous operand  : S[m][32]   16-byte granule g of row m stored at position g ^ ((m >> 1) & 7): the 16 rows of every
+//                           ds_read_b128 lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} land on 16 distinct slots;
 //   M/N-contiguous operand: S[k][BMN]  k-major                                           -> conflict-free ds_read_b32.
 // The contraction of one 32-deep tile is split between half-waves (half h owns k in [16h, 16h+16)), so a lane feeds four
 // consecutive MFMAs from one 16-byte LDS read.  Requires K % 32 == 0 and 16-byte aligned operands (else: generic kernel).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int BMN, bool KC, int NW>
+template <int BMN, bool KC, int NW, int KB>
 struct DmaTile {
-    static constexpr int NI = BMN / 8 / NW;        // 1 KiB pieces per wave per tile (BMN/8 pieces, NW waves)
+    static constexpr int NI = BMN * KB / 256 / NW;  // 1 KiB pieces per wave per k-tile (BMN*KB/256 pieces, NW waves)
+    static constexpr int GR = KB / 4;               // 16-byte granules per row of a K-contiguous image (8 or 4)
+    static constexpr int RP = 256 / KB;             // rows per 1 KiB piece of a K-contiguous image (8 or 16)
+    static_assert(NI >= 1 && (KB == 32 || KB == 16), "unsupported DMA tile");
+    // XOR swizzle of a K-contiguous image: chosen so that the 16 rows of each ds_read_b128 lane group
+    // ({0-3,12-15,20-27} / {4-11,16-19,28-31}) fall on 16 distinct 16-byte slots of the 256-byte bank row.
+    __device__ static __forceinline__ int swz(int m) { return KB == 32 ? ((m >> 1) & 7) : ((m >> 2) & 3); }
     // per-lane source pointer of piece i for the tile starting at k0 (advanced by the caller)
     // MN: extent used for clamping rows (K-contiguous operand) / 16-byte column granules (M/N-contiguous operand);
     // kmax: last valid k row of an M/N-contiguous operand (rows past it are clamped: they meet zero padding of the other
@@ -258,8 +305,8 @@ struct DmaTile {
                                                        int kmax) {
         const int c = wave * NI + i;
         if (KC) {
-            const int m = c * 8 + (lane >> 3);
-            const int g = (lane & 7) ^ ((lane >> 3) & 7);
+            const int m = c * RP + lane / GR;
+            const int g = (lane % GR) ^ swz(m);
             const int row = min(mn0 + m, MN - 1);
             return P + (int64_t)row * ld + k0 + 4 * g;
         } else {
@@ -269,27 +316,34 @@ struct DmaTile {
             return P + (int64_t)min(k0 + k, kmax) * ld + col;
         }
     }
-    __device__ static __forceinline__ int64_t step(int64_t ld) { return KC ? 32 : 32 * ld; }   // floats per k-tile
-    // operand values for k-group sg (k = 16*half + 4*sg + 0..3) of the wave sub-tile starting at row/col w0 + 32*i
-    __device__ static __forceinline__ float4 frag(const float* S, int w0, int i, int l31, int half, int sg) {
+    __device__ static __forceinline__ int64_t step(int64_t ld) { return KC ? KB : KB * ld; }   // floats per k-tile
+    // operand values for k-group sg (k = (KB/2)*half + 4*sg + 0..3) of the wave sub-tile starting at row/col w0 + 32*i
+    __device__ static __forceinline__ float4 frag(const float* __restrict__ S, int w0, int i, int l31, int half, int sg) {
         if (KC) {
             const int row = w0 + 32 * i + l31;
-            return *reinterpret_cast<const float4*>(S + row * 32 + 4 * ((half * 4 + sg) ^ (row & 7)));
+            return *reinterpret_cast<const float4*>(S + row * KB + 4 * ((half * (GR / 2) + sg) ^ swz(row)));
         } else {
-            const float* p = S + (16 * half + 4 * sg) * BMN + w0 + 32 * i + l31;
+            const float* p = S + ((KB / 2) * half + 4 * sg) * BMN + w0 + 32 * i + l31;
             return make_float4(p[0], p[BMN], p[2 * BMN], p[3 * BMN]);
         }
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int VAR, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
-    using TA = DmaTile<BM, A_KC, NW>;
-    using TB = DmaTile<BN, B_KC, NW>;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// KB: k-tile depth (32 or 16), NS: LDS ring depth (NS - 1 k-tiles of DMA in flight under the MFMAs), WPS: waves per SIMD the
+// register budget is sized for (= resident workgroups per CU x NW / 4).
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g) {
+    using TA = DmaTile<BM, A_KC, NW, KB>;
+    using TB = DmaTile<BN, B_KC, NW, KB>;
     constexpr int WM = NW / 2;                         // waves along m (x 2 along n)
     constexpr int TM = BM / WM / 32, TN = BN / 64;
-    constexpr int SA = BM * 32, SB = BN * 32, STAGE = SA + SB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];     // ONE shared object (see guide: DMA + 2nd object de-pipelines)
+    constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
+    constexpr int NPT = TA::NI + TB::NI;               // DMA instructions per wave per k-tile
+    constexpr int NG = KB / 8;                         // 4-deep k-groups per half-wave per k-tile
+    __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];    // ONE shared object (see guide: DMA + 2nd object de-pipelines)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -298,8 +352,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
     const int m0 = tc.m * BM, n0 = tc.n * BN;
     const int kbeg = tc.split * g.kchunk;
     const int kend = min(g.Kloop, kbeg + g.kchunk);
-    const int nk = (kend - kbeg) / BK;
-    const bool tail_here = g.ktail && kend == g.Kloop;       // this workgroup's last k-tile crosses K
+    const int nk = (kend - kbeg) / KB;
+    const bool tail_here = g.ktail && kend == g.Kloop;       // this workgroup's last k-tiles cross K
 
     const float* pa[TA::NI];
     const float* pb[TB::NI];
@@ -317,14 +371,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    int st_in = 0;      // ring slot the next issue() fills
     auto issue = [&](int kt) {
-        float* As = smem + (kt & 1) * STAGE;
+        float* As = smem + st_in * STAGE;
         float* Bs = As + SA;
-        if (tail_here && kt == nk - 1) {      // rare: K tail -- recompute the sources with clamped k rows
+        st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
+        if (tail_here && kbeg + (kt + 1) * KB > g.K) {      // rare: K tail -- recompute the sources with clamped k rows
 #pragma unroll
-            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * BK, wave, lane, i, g.K - 1);
+            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * KB, wave, lane, i, g.K - 1);
 #pragma unroll
-            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * BK, wave, lane, i, g.K - 1);
+            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * KB, wave, lane, i, g.K - 1);
         }
 #pragma unroll
         for (int i = 0; i < TA::NI; ++i) {
@@ -337,20 +393,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
             pb[i] += sb;
         }
     };
-    auto mma = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
-        if (VAR & 2) __builtin_amdgcn_s_setprio(1);
-        if (VAR & 4) {      // k-major order: consecutive MFMAs hit different accumulators
+
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t);
+    int st_out = 0;     // ring slot the MFMAs read
+    for (int kt = 0; kt < nk; ++kt) {
+        // my pieces of tile kt have landed (NS-2 younger tiles may stay in flight); after the barrier everybody's have, and
+        // everybody is done reading the slot tile kt+NS-1 is about to overwrite (it held tile kt-1)
+        if (NS > 2 && nk - kt - 1 >= NS - 2) wait_vmcnt<(NS - 2) * NPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        const float* As = smem + st_out * STAGE;
+        const float* Bs = As + SA;
+        st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+        for (int sg = 0; sg < NG; ++sg) {
+            float4 a[TM], b[TN];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float av = c == 0 ? a[i].x : c == 1 ? a[i].y : c == 2 ? a[i].z : a[i].w;
-                        const float bv = c == 0 ? b[j].x : c == 1 ? b[j].y : c == 2 ? b[j].z : b[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                    }
-        } else {
+            for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -360,50 +424,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_dma_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
-        }
-        if (VAR & 2) __builtin_amdgcn_s_setprio(0);
-    };
-
-    if (nk > 0) issue(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // my pieces of tile kt have landed; after the barrier everybody's have, and everybody is done reading the other stage
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue(kt + 1);
-        const float* As = smem + (kt & 1) * STAGE;
-        const float* Bs = As + SA;
-        if (VAR & 1) {      // fragments of k-group sg+1 are fetched while the MFMAs of group sg run
-            float4 a0[TM], b0[TN], a1[TM], b1[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a0[i] = TA::frag(As, wm0, i, l31, half, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b0[j] = TB::frag(Bs, wn0, j, l31, half, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = TA::frag(As, wm0, i, l31, half, 1);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b1[j] = TB::frag(Bs, wn0, j, l31, half, 1);
-            mma(a0, b0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a0[i] = TA::frag(As, wm0, i, l31, half, 2);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b0[j] = TB::frag(Bs, wn0, j, l31, half, 2);
-            mma(a1, b1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = TA::frag(As, wm0, i, l31, half, 3);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b1[j] = TB::frag(Bs, wn0, j, l31, half, 3);
-            mma(a0, b0);
-            mma(a1, b1);
-        } else {
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                float4 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
-                mma(a, b);
-            }
         }
     }
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
@@ -467,29 +487,25 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.ntiles = g.tiles_m * g.tiles_n;
     dim3 grid(g.ntiles * g.splits), block(256);
     if (g.fast) {
-#define YT_DMA(V, NW)                                                                                                                   \
+#define YT_DMA(NW, KB, NS, WPS)                                                                                                        \
     do {                                                                                                                               \
         dim3 blk(NW * 64);                                                                                                             \
-        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, V, NW>), grid, blk, 0, s, g);                    \
-        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, V, NW>), grid, blk, 0, s, g);             \
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, V, NW>), grid, blk, 0, s, g);             \
-        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, V, NW>), grid, blk, 0, s, g);                                     \
+        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);          \
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);                           \
     } while (0)
-        const char* ev = getenv("YTVLN_GEMM_VARIANT");
-        const int var = ev ? atoi(ev) : 0;
+        static const int cfg = getenv("YTVLN_GEMM_CFG") ? atoi(getenv("YTVLN_GEMM_CFG")) : 0;
         // 128x128 tiles run 8 waves per workgroup (4 per SIMD at 2 workgroups/CU): measured 113 -> 121 TFLOP/s on
         // 16128x1024x1024 and 84 -> 105 on the split-K weight gradients versus 4 waves (barrier coupling across SIMDs).
-        // (Measured and rejected: 256x128 tiles at one workgroup per CU -- lower steady state and more fixed cost; removing
-        //  the per-tile barrier changes nothing, while removing the operand DMA lifts steady state 130 -> 147 TFLOP/s, i.e. the
-        //  residual gap to the MFMA peak is operand traffic, not synchronisation.  See DESIGN.md section 5.)
+        // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
+        //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
+        //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
         if constexpr (BM == 128 && BN == 128) {
-            if (var == 4) YT_DMA(0, 4);
-            else YT_DMA(0, 8);
-        } else if constexpr (BM == 128) {
-            if (var == 8) YT_DMA(0, 8);
-            else YT_DMA(0, 4);
+            if (cfg == 1) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
+            else YT_DMA(8, 32, 2, 4);
         } else {
-            YT_DMA(0, 4);
+            YT_DMA(4, 32, 2, 2);
         }
 #undef YT_DMA
         return 0;
