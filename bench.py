@@ -33,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no sparsity)
 TRAIN_GFLOP_PER_PAIR = 223.9   # algorithmic, T=80 R=288 full config, training = 3 x forward (SURVEY.md 8d / BASELINE.md 3)
 
 WORKLOADS = {
@@ -40,6 +41,8 @@ WORKLOADS = {
     "cfg2_full_pretrain_bs8": ("bert_base_6_layer_6_connect.json", 8, 7, 80, 8, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
     "cfg1_tiny_mlm_bs2": ("tiny_2_2_1.json", 2, 7, 16, 1, 8, dict(masked_language=True)),
     # BASELINE configs[3]: train.py --ranking --shuffle_visual_features, 4 beams + 2 negatives, 7 steps x 36 regions, bs=16/GPU
+    # BASELINE configs[4]: bf16 MFMA path + fused AdamW, long-trajectory stress (16 frames x 36 regions), bs=32/GPU; run with --precision bf16
+    "cfg5_long_traj_bs32": ("bert_base_6_layer_6_connect.json", 32, 7, 80, 16, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
     "cfg4_finetune_rank_bs16": ("bert_base_6_layer_6_connect.json", 16, 6, 80, 7, 36, dict(ranking=True, pretrain=False)),
 }
 
@@ -55,6 +58,9 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the training step as one captured hipGraph (single-GPU runs)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 (default, the headline: the reference's arithmetic) or bf16: dense projections on bf16 MFMA operands "
+                         "with fp32 accumulation, everything else fp32 (BASELINE configs[4])")
     ap.add_argument("--loss-aware-heads", action="store_true",
                     help="(next-row experiment, not the headline) decode only rows that carry a masked-token / masked-region "
                          "target; same losses and gradients, fewer FLOPs than the reference's full decode")
@@ -176,8 +182,10 @@ def main():
             raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev})")
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
 
+    from ytvln import ops as yt_ops
     from ytvln import synth, utils_init
     from ytvln.distributed import DataParallel
+    yt_ops.set_matmul_precision(a.precision)
     from ytvln.lily import Lily
     from ytvln.vilbert import BertConfig
     from ytvln.vilbert_init import get_optimization
@@ -282,7 +290,8 @@ def main():
     out = {
         "metric": "pretrain samples/sec (traj-instr pairs)", "value": round(value, 3), "unit": "pairs/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * elapsed / a.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if a.precision == "fp32" else "bf16 MFMA operands, f32 accumulate / activations / master weights", "data": "synthetic",
         "config": {"workload": a.workload, **({"dist_backend": os.environ["YTVLN_DIST_BACKEND"]} if "YTVLN_DIST_BACKEND" in os.environ else {}), "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
                    "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
                    "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
@@ -291,7 +300,7 @@ def main():
         "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
         "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / a.steps, 2),
     }
-    if "full" in a.workload and T == 80 and frames * boxes == 288 and not a.loss_aware_heads:   # (FLOP count is the full-decode one)
+    if "full" in a.workload and T == 80 and frames * boxes == 288 and not a.loss_aware_heads and a.precision == "fp32":   # (FLOP count is the full-decode one)
         out["model_tflops"] = round(value * TRAIN_GFLOP_PER_PAIR / 1000.0, 2)
         out["model_mfma_frac"] = round(value / world * TRAIN_GFLOP_PER_PAIR / 1000.0 / PEAK_F32_MFMA_TFLOPS, 4)
     if not a.no_kernel_timing and timer.records:
@@ -304,8 +313,13 @@ def main():
             traffic_note = "profiles/round1_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
         except (OSError, KeyError, ValueError):
             pass
-        out["roofline"] = {"kernel": "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": round(ach, 2),
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        peak = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        kname = "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "fp32" else \
+            "ytvln::gemm_dma_kernel<bf16> (v_mfma_f32_32x32x16_bf16) + bf16 operand staging kernels"
+        if a.precision != "fp32":
+            traffic, traffic_note = None, None
+        out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
+                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": traffic, "traffic_source": traffic_note, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
                            "avg_launch_gflop": round(flop / n / 1e9, 3), "measured": roofline_note}
         if a.kernel_table and rank == 0:

@@ -76,6 +76,19 @@ int ytvln_colsum_by_index_f32(const float* x, int64_t ldx, const float* idx_f32,
 int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int M, int H, float* table_grad,
                                int64_t skip_idx, void* stream);
 
+/* Mixed-precision variant of the dense projections (BASELINE config 5: "bf16 MFMA path"): fp32 tensors everywhere in HBM, bf16
+ * operands staged per GEMM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 output and epilogue.  Opt-in (ytvln.ops
+ * .set_matmul_precision("bf16")); the default path and the headline numbers are fp32 (ytvln_gemm_f32).
+ *   ytvln_cast_bf16:  out = bf16(x), round-to-nearest-even; x is [rows, cols] fp32 (ldx).  transpose = 0 -> out [rows][ldo] (the
+ *     contraction index is x's column); transpose = 1 -> out [cols][ldo] with out[c][r] = x[r][c] (contraction index = x's row).
+ *     ldo = contraction length rounded up to 64, tail zero-filled.
+ *   ytvln_gemm_bf16_nt:  C[M,N] (+)= A[M,K] . B[N,K]^T with A, B staged as above (K = the padded contraction length, % 64 == 0);
+ *     bias / aux / epilogue / beta / workspace exactly as ytvln_gemm_f32 (workspace sized by ytvln_gemm_workspace_elems(M,N,K/2,epi)). */
+int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpose, uint16_t* out, int64_t ldo, void* stream);
+int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                       float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
+                       int64_t workspace_elems, void* stream);
+
 /* out[j, :] = x[idx[j], :] (zeros where idx[j] < 0): row gather in front of the loss-aware prediction heads (only rows that
  * carry a masked-language / masked-vision target are decoded; "next" row of SURVEY.md section 8f).  Backward =
  * ytvln_scatter_add_rows_f32 with skip_idx = -1. */

@@ -529,3 +529,36 @@ def test_gemm_zero_padded_tails(dev, lib):
     F.cross_entropy(F.linear(xd, Wd, bd), t).backward()
     for a, r, nme in ((x, xd, "x"), (W, Wd, "W"), (b, bd, "b")):
         assert rel_l2(a.grad, r.grad) < 2e-5, nme
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi", [
+    (256, 192, 128, 0, 1, 0), (300, 200, 100, 0, 1, 0), (300, 200, 100, 0, 0, 0), (300, 200, 100, 1, 0, 0), (260, 132, 72, 1, 1, 0),
+    (512, 384, 256, 0, 1, 1), (200, 1601, 320, 0, 1, 0), (128, 256, 4096, 1, 0, 0)])
+def test_gemm_bf16_staged(dev, lib, M, N, K, ta, tb, epi):
+    """bf16-staged projections (BASELINE config 5): exact product of the bf16-rounded operands, accumulated in fp32.
+    Reference: the same rounded operands multiplied in fp64.  Tolerance = fp32 accumulation noise, 2e-6 * sqrt(K) * |a||b|."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = torch.empty(M, N, device=dev)
+    aux = torch.empty(M, N, device=dev) if epi else None
+    ops.set_matmul_precision("bf16")
+    try:
+        ops._gemm(A, A.stride(0), ta, B, B.stride(0), tb, C, N, M, N, K, bias=bias, aux=aux, ldaux=N, epi=epi)
+    finally:
+        ops.set_matmul_precision("fp32")
+    Ar = (A.t() if ta else A).bfloat16().double().cpu()
+    Br = (B if tb else B.t()).bfloat16().double().cpu()
+    ref = Ar @ Br.t() + bias.double().cpu()
+    tol = 2e-6 * (K ** 0.5) * 4.0 + 1e-5
+    if epi:
+        assert float((aux.double().cpu() - ref).abs().max()) < tol
+        ref = torch.nn.functional.gelu(ref)
+    err = float((C.double().cpu() - ref).abs().max())
+    assert err < tol, (err, tol)
+    # and it is NOT the fp32 product: the staging really rounds (guards against a silent fp32 fallback)
+    full = (A.t() if ta else A).double().cpu() @ (B if tb else B.t()).double().cpu().t() + bias.double().cpu()
+    if not epi:
+        assert float((C.double().cpu() - full).abs().max()) > 1e-3

@@ -94,6 +94,11 @@ __device__ __forceinline__ LaneOff make_lane_off(int l31, int half) {
     return o;
 }
 
+// LDS reads in the tile loops go through __restrict__ parameters: a ds_read without alias information makes hipcc emit
+// s_waitcnt vmcnt(0) in front of it whenever an LDS-DMA is in flight (it might alias the DMA's destination), which drains the
+// prefetch of the next tile in the middle of the current one.
+__device__ __forceinline__ float4 lds4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+
 // per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1 (zero past nrows / past d)
 template <int DP>
 __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __restrict__ base, int64_t ld, int64_t row_base,
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         float mt = -INFINITY;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 mk = *reinterpret_cast<const float4*>(Mrow + j0 + 8 * g + 4 * half);
+            const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
             P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
             P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
         }
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         float dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 mk = *reinterpret_cast<const float4*>(Mrow + j0 + 8 * g + 4 * half);
+            const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
             const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -421,8 +426,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         float Pt[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 ls = *reinterpret_cast<const float4*>(Lrow + i0 + 8 * g + 4 * half);
-            const float4 ds = *reinterpret_cast<const float4*>(Drow + i0 + 8 * g + 4 * half);
+            const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
+            const float4 ds = lds4(Drow + i0 + 8 * g + 4 * half);
             const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

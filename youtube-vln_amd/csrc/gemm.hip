@@ -334,8 +334,16 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // KB: k-tile depth (32 or 16), NS: LDS ring depth (NS - 1 k-tiles of DMA in flight under the MFMAs), WPS: waves per SIMD the
 // register budget is sized for (= resident workgroups per CU x NW / 4).
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS>
+//
+// BF16 = true: the operands are bf16 matrices (both K-contiguous) seen as float arrays of half the width -- the byte geometry
+// of tiles, DMA pieces and swizzle is unchanged; a 16-byte granule now holds the 8 consecutive k one lane feeds to
+// v_mfma_f32_32x32x16_bf16, so every k-group is ONE matrix instruction per accumulator instead of four (granule 4*half + sg:
+// the k-slots of the two half-waves are any fixed, identical split for A and B).  Accumulation and epilogue stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g) {
+    static_assert(!BF16 || (A_KC && B_KC && KB == 32), "bf16 operands are staged K-contiguous");
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
     constexpr int WM = NW / 2;                         // waves along m (x 2 along n)
@@ -419,10 +427,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    if constexpr (BF16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                             acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
                 }
         }
     }
@@ -519,6 +532,82 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     return 0;
 }
 
+
+// ---- bf16 operand staging ---------------------------------------------------------------------------------------------------
+// out[r][c] = bf16(x[r][c]) for c < cols, 0 for cols <= c < ldo  (round to nearest even; ldo = cols rounded up to 64 so the GEMM's
+// 64-deep k-tiles never read past the row).  One thread converts 8 consecutive columns (two 16-byte loads -> one 16-byte store).
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t bf16_pack(float lo, float hi) { return bf16_rne(lo) | (bf16_rne(hi) << 16); }
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, uint16_t* __restrict__ out,
+                                                        int64_t ldo, int vec) {
+    const int g8 = (int)(ldo >> 3);
+    const int64_t total = (int64_t)rows * g8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / g8), c = (int)(i % g8) << 3;
+        const float* p = x + (int64_t)r * ldx + c;
+        float v[8];
+        if (vec && c + 8 <= cols) {
+            const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c + u < cols ? p[u] : 0.f;
+        }
+        uint4 o = make_uint4(bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3]), bf16_pack(v[4], v[5]), bf16_pack(v[6], v[7]));
+        *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + c) = o;
+    }
+}
+
+// out[c][r] = bf16(x[r][c]) for r < rows, 0 for rows <= r < ldo: the transposing variant for operands whose contraction index
+// is the ROW of the fp32 matrix (dY^T, X^T of the weight-gradient GEMM; W^T of the input-gradient GEMM).  64 x 64 tiles through
+// LDS: coalesced 16-byte loads along c, 16-byte stores of 8 consecutive r.
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, uint16_t* __restrict__ out,
+                                                          int64_t ldo, int vec) {
+    __shared__ float tile[64][65];
+    const int tiles_c = (cols + 63) >> 6;
+    const int r0 = (blockIdx.x / tiles_c) << 6, c0 = (blockIdx.x % tiles_c) << 6;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                       // 64 rows x 16 float4
+        const int idx = tid + 256 * it, r = idx >> 4, c = (idx & 15) << 2;
+        const int gr = r0 + r, gc = c0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < rows) {
+            const float* p = x + (int64_t)gr * ldx + gc;
+            if (vec && gc + 4 <= cols) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (gc < cols) v.x = p[0];
+                if (gc + 1 < cols) v.y = p[1];
+                if (gc + 2 < cols) v.z = p[2];
+                if (gc + 3 < cols) v.w = p[3];
+            }
+        }
+        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                       // 64 output rows (c) x 8 groups of 8 r
+        const int idx = tid + 256 * it, c = idx >> 3, r = (idx & 7) << 3;
+        if (c0 + c < cols && r0 + r < ldo) {
+            uint4 o = make_uint4(bf16_pack(tile[r][c], tile[r + 1][c]), bf16_pack(tile[r + 2][c], tile[r + 3][c]),
+                                 bf16_pack(tile[r + 4][c], tile[r + 5][c]), bf16_pack(tile[r + 6][c], tile[r + 7][c]));
+            *reinterpret_cast<uint4*>(out + (int64_t)(c0 + c) * ldo + r0 + r) = o;
+        }
+    }
+}
+
+static void launch_bf16(GemmArgs& g, hipStream_t s) {
+    g.tiles_m = (int)cdiv(g.M, 128);
+    g.tiles_n = (int)cdiv(g.N, 128);
+    g.ntiles = g.tiles_m * g.tiles_n;
+    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, true, true, 8, 32, 2, 4, true>), dim3(g.ntiles * g.splits), dim3(512), 0, s, g);
+}
+
 }  // namespace ytvln
 
 using namespace ytvln;
@@ -578,5 +667,57 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         else launch_tile<64, 64>(g, transA, transB, s);
     }
     YT_LAUNCH_CHECK("gemm_f32");
+    return 0;
+}
+
+extern "C" int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpose, uint16_t* out, int64_t ldo, void* stream) {
+    YT_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols, "cast_bf16: bad argument");
+    const int contract = transpose ? rows : cols;
+    YT_REQUIRE(ldo % 64 == 0 && ldo >= contract && ldo < contract + 64, "cast_bf16: ldo must be the contraction length rounded up to 64");
+    YT_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "cast_bf16: output must be 16-byte aligned");
+    const int vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
+    hipStream_t s = as_stream(stream);
+    if (!transpose) {
+        const int64_t total = (int64_t)rows * (ldo >> 3);
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, s, x, ldx, rows, cols, out, ldo, vec);
+    } else {
+        const int64_t tiles = cdiv(ldo, 64) * cdiv(cols, 64);
+        YT_REQUIRE(tiles < (1ll << 31), "cast_bf16: matrix too large");
+        hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, rows, cols, out, ldo, vec);
+    }
+    YT_LAUNCH_CHECK("cast_bf16");
+    return 0;
+}
+
+extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                                  float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
+                                  int64_t workspace_elems, void* stream) {
+    YT_REQUIRE(A && B && C, "gemm_bf16: null operand");
+    YT_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16: K must be a positive multiple of 64 (stage operands with ytvln_cast_bf16)");
+    YT_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N, "gemm_bf16: bad leading dimension");
+    YT_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0, "gemm_bf16: operands must be 16-byte aligned");
+    YT_REQUIRE(epilogue >= YTVLN_EPI_NONE && epilogue <= YTVLN_EPI_MUL_DRELU, "gemm_bf16: bad epilogue %d", epilogue);
+    YT_REQUIRE(!(epilogue >= YTVLN_EPI_MUL_DGELU) || aux, "gemm_bf16: epilogue %d needs aux", epilogue);
+    GemmArgs g;
+    // the kernel sees the bf16 matrices as float matrices of half the width
+    g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias = bias; g.aux = aux;
+    g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
+    g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
+    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N;
+    g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
+    const int want = plan_splits(M, N, K / 2, epilogue);
+    if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
+        g.kchunk = (int)cdiv(cdiv(g.Kloop, want), BK) * BK;
+        g.splits = (int)cdiv(g.Kloop, g.kchunk);
+        g.ws = workspace;
+    }
+    hipStream_t s = as_stream(stream);
+    launch_bf16(g, s);
+    if (g.splits > 1) {
+        const int64_t total = (int64_t)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
+                           ldc, bias, M, N, g.splits, beta);
+    }
+    YT_LAUNCH_CHECK("gemm_bf16_nt");
     return 0;
 }

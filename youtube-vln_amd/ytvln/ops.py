@@ -97,12 +97,46 @@ class DropoutState:
 _WS_CACHE = {}
 
 
+_MATMUL_PRECISION = "fp32"
+
+
+def set_matmul_precision(mode: str) -> None:
+    """"fp32" (default, the reference's arithmetic) or "bf16": dense projections stage their operands in bf16 and run on
+    v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE config 5); everything else -- attention, LayerNorm, losses,
+    master weights, optimizer -- stays fp32.  Process-wide switch, read at call time."""
+    global _MATMUL_PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"matmul precision must be 'fp32' or 'bf16', got {mode!r}")
+    _MATMUL_PRECISION = mode
+
+
+def get_matmul_precision() -> str:
+    return _MATMUL_PRECISION
+
+
+def _stage_bf16(X: Tensor, ld: int, rows: int, cols: int, transpose: bool) -> Tuple[Tensor, int]:
+    """bf16 copy of the fp32 matrix at X with the contraction index made contiguous and zero-padded to a multiple of 64."""
+    contract, other = (rows, cols) if transpose else (cols, rows)
+    ldo = (contract + 63) // 64 * 64
+    out = torch.empty((other, ldo), dtype=torch.bfloat16, device=X.device)
+    call("ytvln_cast_bf16", _ptr(X), ld, rows, cols, int(transpose), _ptr(out), ldo, _stream())
+    return out, ldo
+
+
 def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0):
-    key = (M, N, K, epi)
+    bf16 = _MATMUL_PRECISION == "bf16" and M >= 64 and N >= 64 and K >= 64
+    Kw = (K + 63) // 64 * 32 if bf16 else K        # contraction length in 4-byte words, as the split-K planner counts it
+    key = (M, N, Kw, epi)
     need = _WS_CACHE.get(key)
     if need is None:
-        need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, K, epi))
+        need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, Kw, epi))
     ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
+    if bf16:
+        Ab, la = _stage_bf16(A, lda, K, M, True) if transA else _stage_bf16(A, lda, M, K, False)       # -> [M][Kp]
+        Bb, lb = _stage_bf16(B, ldb, N, K, False) if transB else _stage_bf16(B, ldb, K, N, True)       # -> [N][Kp]
+        call("ytvln_gemm_bf16_nt", _ptr(Ab), la, _ptr(Bb), lb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, M, N, la, epi, float(beta),
+             _ptr(ws), need, _stream())
+        return
     call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
          M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _stream())
 
