@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the training step as one captured hipGraph (single-GPU runs)")
+                    help="auto|on: replay the step from hipGraphs (1 GPU: one graph; N GPUs: two graphs around the RCCL all-reduce), falling back to eager launches if capture fails; off: eager launches")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 (default, the headline: the reference's arithmetic) or bf16: dense projections on bf16 MFMA operands "
                          "with fp32 accumulation, everything else fp32 (BASELINE configs[4])")
@@ -220,33 +220,52 @@ def main():
     def step(i):
         return utils_init.train_step(runner, opt, sched, batch, args, i, all_options=True, loss_aware_heads=a.loss_aware_heads)
 
-    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1)
+    use_graph = a.graph in ("on", "auto")
     execution = "eager launches"
     eager_step = step
     if use_graph:
-        # hipGraph replay of the whole step (forward, losses, backward, fused AdamW): the host only uploads the LR-dependent
-        # hyper-parameters and advances the schedule.  Dropout masks still change every replay (device-side counter).
-        assert world == 1, "--graph is a single-GPU mode"
+        # world == 1: hipGraph replay of the whole step (forward, losses, backward, fused AdamW); the host only uploads the
+        # LR-dependent hyper-parameters and advances the schedule.  world > 1: two graphs (forward+backward | AdamW) with the
+        # RCCL gradient all-reduce between them, outside any graph (ytvln.distributed.GraphedTrainStep).  Dropout masks still
+        # change every replay (device-side counter).  Capture is an optimisation, never a requirement: any rank that cannot
+        # capture sends every rank back to eager launches (the collective sizes differ between the two modes).
+        ok = True
         try:
             for i in range(2):                                 # eager steps: build the optimizer arenas, warm the allocator
                 eager_step(i)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            static = {}
-            with torch.cuda.graph(graph):
-                static["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
-                                                             loss_aware_heads=a.loss_aware_heads)
-            torch.cuda.synchronize()
+            if world == 1:
+                graph = torch.cuda.CUDAGraph()
+                static = {}
+                with torch.cuda.graph(graph):
+                    static["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
+                                                                 loss_aware_heads=a.loss_aware_heads)
+                torch.cuda.synchronize()
 
-            def step(i):   # noqa: F811
-                opt.prepare_replay()
-                graph.replay()
-                sched.step()
-                return static["loss"], None
+                def graph_step(i):
+                    opt.prepare_replay()
+                    graph.replay()
+                    sched.step()
+                    return static["loss"], None
+            else:
+                from ytvln.distributed import GraphedTrainStep
+                gs = GraphedTrainStep(runner, opt, lambda: utils_init.train_step(
+                    runner, opt, None, batch, args, 0, all_options=True, loss_aware_heads=a.loss_aware_heads, optimizer_step=False)[0])
 
-            execution = "hipGraph replay of the captured step"
-        except Exception as e:   # capture is an optimisation, never a requirement
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+                def graph_step(i):
+                    return gs.step(sched), None
+        except Exception as e:
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            ok = False
+        if world > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0.5)
+        if ok:
+            step = graph_step
+            execution = "hipGraph replay of the captured step" if world == 1 else \
+                "two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them"
+        else:
             torch.cuda.synchronize()
             opt.zero_grad()
             use_graph = False

@@ -37,7 +37,7 @@ def _batch(rank, dev):
     return synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=40 + rank, ignore_rank_frac=0.0), dev)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="eager"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
@@ -55,24 +55,35 @@ def _worker(rank, world, port, q):
     opt, sched, _, _ = get_optimization(args, model, 10, None)
     dp.attach(opt)
     batch = _batch(rank, dev)
-    for step in range(3):
-        U.train_step(dp, opt, sched, batch, args, step, all_options=True)
+    if mode == "eager":
+        for step in range(3):
+            U.train_step(dp, opt, sched, batch, args, step, all_options=True)
+    else:       # one eager step, then two replays of the two-graph step with the exchange between the graphs
+        U.train_step(dp, opt, sched, batch, args, 0, all_options=True)
+        gs = D.GraphedTrainStep(dp, opt, lambda: U.train_step(dp, opt, None, batch, args, 0, all_options=True, optimizer_step=False)[0],
+                                bucket_bytes=64 << 10)
+        assert len(gs._slices) > 1
+        for step in range(2):
+            loss = gs.step(sched)
+        assert torch.isfinite(loss).item()
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     assert torch.equal(both[0], both[1]), "replicas diverged"
     assert dp._reducer is not None and len(dp._reducer.buckets) > 1
+    assert all(opt.state[p]["step"] == 3 for p in model.parameters() if p in opt.state and "step" in opt.state[p])
     if rank == 0:
         q.put(flat.numpy())
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_average(dev, lib):
+@pytest.mark.parametrize("mode", ["eager", "graphed"])
+def test_two_ranks_match_single_process_average(dev, lib, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)

@@ -179,6 +179,62 @@ class DataParallel(nn.Module):
         self._reducer.finish()
 
 
+class GraphedTrainStep:
+    """A training step as TWO hipGraphs with the gradient exchange between them:
+
+        graph A   forward, losses, backward, adoption of the stray gradients into the flat arena
+        eager     all-reduce(SUM) of the arena in `bucket_bytes` slices over RCCL   (world > 1; never captured)
+        graph B   fused AdamW (1/world folded in) 
+
+    The host enqueues two graph launches and a handful of collectives per step instead of ~1500 kernels, so N processes do
+    not compete for host cores; RCCL calls stay ordinary stream work, exactly as in the eager path.  (The eager path overlaps
+    the exchange with backward; here it follows backward -- 1 GB over xGMI, a few ms against a >100 ms step.)
+
+    `fwd_bwd()` must run forward + backward only (utils_init.train_step(..., optimizer_step=False)) on STATIC input tensors and
+    return the loss tensor; refill the inputs in place between steps.  Run >= 1 eager step first (arenas, allocator warm-up)."""
+
+    def __init__(self, model: nn.Module, optimizer, fwd_bwd: Callable[[], torch.Tensor], bucket_bytes: int = 256 << 20, group=None):
+        self.opt, self.group, self.bucket_bytes = optimizer, group, bucket_bytes
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dp = model if isinstance(model, DataParallel) else None
+        if optimizer.flat_grad() is None:
+            raise RuntimeError("run at least one eager training step before capturing")
+        optimizer.zero_grad()
+        optimizer.grad_scale = 1.0 / self.world
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.require_backward_grad_sync = False       # the bucket hooks must not launch collectives into the capture
+        try:
+            # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
+            self.graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+                self.loss = fwd_bwd()
+                optimizer.capture_adopt()
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
+                optimizer.capture_update()
+        finally:
+            if dp is not None:
+                dp.require_backward_grad_sync = True
+        optimizer.zero_grad()
+        torch.cuda.synchronize()
+        flat = optimizer.flat_grad()
+        cap = max(1, bucket_bytes // flat.element_size())
+        self._slices = [(lo, min(lo + cap, flat.numel())) for lo in range(0, flat.numel(), cap)]
+
+    def step(self, scheduler=None) -> torch.Tensor:
+        self.graph_a.replay()
+        if self.world > 1:
+            flat = self.opt.flat_grad()
+            for lo, hi in self._slices:
+                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self.opt.prepare_replay()
+        self.graph_b.replay()
+        if scheduler is not None:
+            scheduler.step()
+        return self.loss
+
+
 def wrap_distributed_model(model: nn.Module, local_rank: int = -1, **kw) -> nn.Module:
     """utils/distributed.py:97-104."""
     if local_rank != -1 and dist.is_initialized() and dist.get_world_size() > 1:

@@ -227,6 +227,29 @@ class AdamW(Optimizer):
         self._launch_kernels()
         return loss
 
+    # -- two-phase capture for data-parallel runs (ytvln.distributed.GraphedTrainStep): the gradient exchange sits between the
+    #    "gradients are complete in the arena" point and the update, and stays outside any graph.
+    def capture_adopt(self):
+        """Inside a capture, after backward: record the copies that bring the few non-arena gradients into the flat arena."""
+        if not torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("capture_adopt() is only meaningful while capturing a hipGraph")
+        if self._arena is None or self._launch is None:
+            raise RuntimeError("run at least one eager optimizer step before capturing a step into a graph")
+        if self._arena["ids"] != [id(p) for _, p in self._members()]:
+            raise RuntimeError("the set of parameters receiving gradients changed; cannot capture")
+        self._ensure_arena()
+
+    def capture_update(self):
+        """Inside a capture: record the fused AdamW kernels (hyper-parameters come from prepare_replay())."""
+        if not torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("capture_update() is only meaningful while capturing a hipGraph")
+        self._written.clear()
+        self._launch_kernels()
+
+    def flat_grad(self):
+        """The flat fp32 gradient arena (None before the first optimizer step)."""
+        return None if self._arena is None else self._arena["g"]
+
     def prepare_replay(self):
         """Call before each replay of a captured training step (after scheduler.step() set the new learning rate)."""
         self._upload_hyper()

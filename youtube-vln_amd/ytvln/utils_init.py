@@ -165,7 +165,7 @@ def _loss_aware_step(model, batch, args, all_options, capacity_frac):
 
 
 def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=None, all_options=None,
-               loss_aware_heads: bool = False, capacity_frac: float = 0.25):
+               loss_aware_heads: bool = False, capacity_frac: float = 0.25, optimizer_step: bool = True):
     """One iteration of train_epoch's body (utils_init.py:199-239): forward, loss composition in the reference's order,
     backward, and -- every gradient_accumulation_steps -- optimizer.step(); scheduler.step(); zero_grad().
     Returns (loss, reduced_metrics) as device tensors; never synchronises the host."""
@@ -191,6 +191,8 @@ def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=N
     if accum > 1:
         loss = loss / accum
     loss.backward()
+    if not optimizer_step:          # forward/backward only (ytvln.distributed.GraphedTrainStep captures the update separately)
+        return loss.detach(), reduced_metrics
     if (step + 1) % accum == 0:
         optimizer.step()
         if scheduler is not None:
