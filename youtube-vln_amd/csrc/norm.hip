@@ -223,6 +223,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// 16-byte variant: a lane owns 4 consecutive columns, a wave sweeps 1 KiB of a row per load, 4 rows in flight per lane.
+__global__ __launch_bounds__(256) void colsum_v4_kernel(const float* __restrict__ x, int64_t ldx, int M, int N4,
+                                                        float* __restrict__ out, int64_t ldo, int rpb) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rpb, r1 = min(r0 + rpb, M);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (c4 < N4) {
+        const float4* p = reinterpret_cast<const float4*>(x) + c4;
+        const int64_t ld4 = ldx >> 2;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            const float4 v0 = p[(int64_t)r * ld4], v1 = p[(int64_t)(r + 4) * ld4], v2 = p[(int64_t)(r + 8) * ld4], v3 = p[(int64_t)(r + 12) * ld4];
+            a0 = f4add(a0, v0); a1 = f4add(a1, v1); a2 = f4add(a2, v2); a3 = f4add(a3, v3);
+        }
+        for (; r < r1; r += 4) a0 = f4add(a0, p[(int64_t)r * ld4]);
+    }
+    red[rl][lane] = f4add(f4add(a0, a1), f4add(a2, a3));
+    __syncthreads();
+    if (rl == 0 && c4 < N4)
+        reinterpret_cast<float4*>(out + (int64_t)blockIdx.y * ldo)[c4] = f4add(f4add(red[0][lane], red[1][lane]), f4add(red[2][lane], red[3][lane]));
+}
+
 __global__ __launch_bounds__(256) void colsum_by_index_kernel(const float* __restrict__ x, int64_t ldx,
                                                               const float* __restrict__ idx_f, int64_t idx_stride,
                                                               const int64_t* __restrict__ idx_i, int M, int N, int KT,
@@ -418,8 +442,12 @@ extern "C" int ytvln_colsum_f32(const float* x, int64_t ldx, int M, int N, float
     YT_REQUIRE(x && out && M >= 0 && N > 0 && rows_per_block > 0, "colsum: bad argument");
     const int nb = (int)std::max<int64_t>(1, cdiv(M, rows_per_block));
     YT_REQUIRE(nb <= 65535, "colsum: too many row blocks (%d)", nb);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64), nb), dim3(256), 0, as_stream(stream), x, ldx, M, N, out, ldo,
-                       rows_per_block);
+    if (N % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && al16(x) && al16(out))
+        hipLaunchKernelGGL(colsum_v4_kernel, dim3((unsigned)cdiv(N / 4, 64), nb), dim3(256), 0, as_stream(stream), x, ldx, M, N / 4, out,
+                           ldo, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64), nb), dim3(256), 0, as_stream(stream), x, ldx, M, N, out, ldo,
+                           rows_per_block);
     YT_LAUNCH_CHECK("colsum");
     return 0;
 }

@@ -146,8 +146,8 @@ def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> 
     e.g. a gradient-arena slot)."""
     first = True
     while True:
-        nstrips = (N + 63) // 64
-        nb = max(1, min((M + 31) // 32, max(1, 2048 // nstrips))) if first else 1      # two stages at most
+        nstrips = (N + 255) // 256          # the kernel sweeps 256-column strips (16 bytes per lane) whenever N % 4 == 0
+        nb = max(1, min((M + 31) // 32, max(1, 1024 // nstrips))) if first else 1      # two stages at most
         first = False
         rpb = (M + nb - 1) // nb
         nb = (M + rpb - 1) // rpb
