@@ -113,61 +113,34 @@ __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __
 }
 
 // acc (32x32) = Xs-tile (rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T
-// The 64 MFMAs form one dependent chain, so the LDS fragment of group g+1 is fetched BEFORE the four MFMAs of group g are
-// issued (register double buffer): otherwise every fourth MFMA waits a full ds_read_b128 round trip.
 template <int DP>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // granule index within the half = g; its low 3 bits are swizzled (lane-constant table), the rest is an immediate
-    constexpr int G = DP / 8;                 // 4-deep k-groups per half-wave (even)
-    auto frag = [&](int g) { return *reinterpret_cast<const float4*>(Xs + lo.rows[g & 7] + (g & ~7) * 4); };
-    float4 xa = frag(0), xb = frag(1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-    for (int g = 0; g < G; g += 2) {
-        acc = MFMA(xa.x, R[4 * g], acc);
-        acc = MFMA(xa.y, R[4 * g + 1], acc);
-        acc = MFMA(xa.z, R[4 * g + 2], acc);
-        acc = MFMA(xa.w, R[4 * g + 3], acc);
-        if (g + 2 < G) xa = frag(g + 2);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // pin: 4 MFMAs, then the LDS read two groups ahead
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        acc = MFMA(xb.x, R[4 * g + 4], acc);
-        acc = MFMA(xb.y, R[4 * g + 5], acc);
-        acc = MFMA(xb.z, R[4 * g + 6], acc);
-        acc = MFMA(xb.w, R[4 * g + 7], acc);
-        if (g + 3 < G) xb = frag(g + 3);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    for (int s4 = 0; s4 < DP / 2; s4 += 4) {
+        // granule index within the half = s4/4; its low 3 bits are swizzled (lane-constant table), the rest is an immediate
+        const float4 x = *reinterpret_cast<const float4*>(Xs + lo.rows[(s4 >> 2) & 7] + ((s4 >> 2) & ~7) * 4);
+        acc = MFMA(x.x, R[s4], acc);
+        acc = MFMA(x.y, R[s4 + 1], acc);
+        acc = MFMA(x.z, R[s4 + 2], acc);
+        acc = MFMA(x.w, R[s4 + 3], acc);
     }
     return acc;
 }
 
 // acc[c] (dcol x lane-col) += Xs^T (rows = dcol, contraction over the 32 tile rows in krow order) . P (own registers)
-// r-outer / c-inner: the DP/32 accumulators are independent chains, so consecutive MFMAs never wait on each other, and the
-// operands of step r+1 are fetched before the MFMAs of step r are issued.  (All DP/32 column blocks are computed: blocks past
-// d only ever reach accumulator columns that are never stored.)
 template <int DP>
 __device__ __forceinline__ void mma_cols(f32x16 (&acc)[DP / 32], const float* __restrict__ Xs, const float (&P)[16],
                                          const LaneOff& lo, int d) {
-    constexpr int NC = DP / 32;
-    float x[NC], xn[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) x[c] = Xs[lo.cols[0] + c * 32];
+    for (int c = 0; c < DP / 32; ++c) {
+        if (c * 32 < d) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {           // row = (r&3) + 8*(r>>2) + 4*half: (row&7) only depends on (r&3, half)
-        if (r + 1 < 16) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) xn[c] = Xs[lo.cols[(r + 1) & 3] + 8 * ((r + 1) >> 2) * DP + c * 32];
+            for (int r = 0; r < 16; ++r)     // row = (r&3) + 8*(r>>2) + 4*half: (row&7) only depends on (r&3, half)
+                acc[c] = MFMA(Xs[lo.cols[r & 3] + 8 * (r >> 2) * DP + c * 32], P[r], acc[c]);
         }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = MFMA(x[c], P[r], acc[c]);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) x[c] = xn[c];
-        __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);     // LDS reads of step r+1 first, then the NC MFMAs of step r
-        __builtin_amdgcn_sched_group_barrier(0x008, NC, 0);
     }
 }
 
