@@ -43,6 +43,8 @@ WORKLOADS = {
     # BASELINE configs[3]: train.py --ranking --shuffle_visual_features, 4 beams + 2 negatives, 7 steps x 36 regions, bs=16/GPU
     # BASELINE configs[4]: bf16 MFMA path + fused AdamW, long-trajectory stress (16 frames x 36 regions), bs=32/GPU; run with --precision bf16
     "cfg5_long_traj_bs32": ("bert_base_6_layer_6_connect.json", 32, 7, 80, 16, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
+    # inference re-ranking (test.py:144-192): 30 candidate beams of one instruction, T=60, 8 viewpoints x 101 regions, forward only
+    "infer_rerank_beam30": ("bert_base_6_layer_6_connect.json", 1, 30, 60, 8, 101, dict(ranking=True, pretrain=False)),
     "cfg4_finetune_rank_bs16": ("bert_base_6_layer_6_connect.json", 16, 6, 80, 7, 36, dict(ranking=True, pretrain=False)),
 }
 
@@ -217,10 +219,19 @@ def main():
     if not a.no_kernel_timing:
         timer.install()
 
-    def step(i):
-        return utils_init.train_step(runner, opt, sched, batch, args, i, all_options=True, loss_aware_heads=a.loss_aware_heads)
+    infer = a.workload.startswith("infer")
+    if infer:
+        model.eval()
+        inputs = utils_init.get_model_input(batch, True)
 
-    use_graph = a.graph in ("on", "auto")
+        def step(i):      # forward only (test.py:144-166): scores of the candidate paths stay on the device
+            with torch.no_grad():
+                return runner(*inputs)["ranking"].sum(), None
+    else:
+        def step(i):
+            return utils_init.train_step(runner, opt, sched, batch, args, i, all_options=True, loss_aware_heads=a.loss_aware_heads)
+
+    use_graph = a.graph in ("on", "auto") and not infer
     execution = "eager launches"
     eager_step = step
     if use_graph:
@@ -294,6 +305,8 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss)
     assert np.isfinite(final_loss), "training diverged"
+    if infer:
+        execution = "eager launches, eval mode, forward only"
     roofline_note = "HIP events around every GEMM launch during the timed steps"
     if use_graph and not a.no_kernel_timing:
         n_prof = min(a.steps, 3)

@@ -453,3 +453,38 @@ def test_g2_full_model_bf16_projections(dev, lib):
         if abs(got - ref) > 5e-2 * ref + 1e-6:
             bad.append((n, got, float(ref)))
     assert not bad, bad[:5]
+
+
+def test_inference_rerank_shapes_match_oracle(dev, lib):
+    """The re-ranking inference path (test.py:144-192) at the reference's inference shapes: 30 candidate beams per instruction,
+    R = 8 viewpoints x 101 regions = 808 (not a multiple of the 32-row attention tiles), T = 60, forward only, eval mode -- on the
+    tiny configuration so the CPU oracle finishes in seconds.  Ranking scores within 1e-4 of the oracle; eval_epoch / convert_scores
+    pick the same beams as an argmax over the oracle's scores."""
+    import vilbert_ref as O
+    from ytvln import synth
+    from ytvln import utils_init as U
+    args = args_ns(ranking=True, pretrain=False)
+    model, W = build_lily(dev, "tiny_2_2_1.json", args, seed=31)
+    model.eval()
+    nb = synth.make_batch(bs=2, K=30, T=60, frames=8, boxes=101, seed=77, finetune_heading=True, ignore_rank_frac=0.0)
+    nb[13][1, 25:] = False                       # the second instruction has only 25 candidates (ragged opt_mask)
+    nb[12] = np.array([[4051, 0], [4051, 2]], np.int64)         # test-time loaders put (path id, instruction index) here
+    batch_cpu = synth.to_torch(nb)
+    scores = U.eval_epoch(model, [batch_cpu], args)
+    assert [s[0] for s in scores] == ["4051_0", "4051_2"]
+    S = {k: torch.from_numpy(v).clone() for k, v in W.items()}
+    cfgd = cfg_dict("tiny_2_2_1.json", **ZERO_DROP)
+    ids, feat, loc, seg, imask, vmask = O.model_input(batch_cpu)
+    with torch.no_grad():
+        ref = O.lily_forward(S, O.RefConfig(**cfgd), O.TaskFlags(ranking=True), ids, feat, loc, seg, imask, vmask)["ranking"].squeeze(1)
+    ref = O.pad_packed(ref, batch_cpu[13])
+    got = torch.tensor([s[1] for s in scores])
+    valid = batch_cpu[13]
+    assert float((got - ref)[valid].abs().max()) < 1e-4, float((got - ref)[valid].abs().max())
+    assert torch.equal(got[~valid], ref[~valid])          # padded candidates carry pad_packed's filler in both
+    beam_data = [{"instr_id": i, "ranked_paths": [[f"vp{i}_{b}_{k}" for k in range(3)] for b in range(30)], "exploration_path": ["e0", "e1"]}
+                 for i in ("4051_0", "4051_2")]
+    out = U.convert_scores(scores, beam_data, add_exploration_path=True)
+    for row, o in zip(ref, out):
+        best = int(torch.argmax(row))
+        assert o["trajectory"] == [["e0"], ["e1"]] + beam_data[0 if o["instr_id"] == "4051_0" else 1]["ranked_paths"][best]

@@ -326,3 +326,50 @@ def val_epoch(epoch: int, model, tag, data_loader, writer, default_gpu, args, gl
         writer.add_scalar(f"loss/{task}_{tag}", float(stats[1] / max(steps, 1)), global_step=global_step)
         writer.add_scalar(f"accuracy/{task}_{tag}", float(success_rate), global_step=global_step)
     return success_rate
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# inference re-ranking (test.py:144-192): forward only, eval mode, ranking head
+# ------------------------------------------------------------------------------------------------------------------
+def get_instr_ids(batch) -> List[str]:
+    """test.py:200-202: "<path id>_<instruction index>" per dataset item."""
+    return [f"{int(item[0])}_{int(item[1])}" for item in batch[12].tolist()]
+
+
+def eval_epoch(model, data_loader, args, all_options=None):
+    """test.py:144-166 -> [(instr_id, [score per candidate path])].  One device->host copy per batch (the scores)."""
+    device = next(model.parameters()).device
+    model.eval()
+    all_scores = []
+    with torch.no_grad():
+        for batch in data_loader:
+            instr_ids = get_instr_ids(batch)
+            if getattr(args, "random_testing", False):
+                vil_logit = torch.rand(batch[0].shape)
+            else:
+                batch = _to_device(batch, device)
+                output = model(*get_model_input(batch, all_options))
+                opt_mask = get_mask_options(batch)
+                scores = output["ranking"].squeeze(1)
+                vil_logit = scores.view(opt_mask.shape) if all_options else pad_packed(scores, opt_mask)
+            for instr_id, logit in zip(instr_ids, vil_logit.tolist()):
+                all_scores.append((instr_id, logit))
+    return all_scores
+
+
+def convert_scores(all_scores, beam_data, add_exploration_path: bool = False):
+    """test.py:169-192: pick the best-scored beam per instruction.  `beam_data` = the parsed beam file (list of dicts with
+    instr_id / ranked_paths / exploration_path)."""
+    beams_of = {item["instr_id"]: item["ranked_paths"] for item in beam_data}
+    explore = {item["instr_id"]: [[vp] for vp in item["exploration_path"]] for item in beam_data} if add_exploration_path else {}
+    output = []
+    for instr_id, scores in all_scores:
+        idx = max(range(len(scores)), key=scores.__getitem__)
+        beams = beams_of[instr_id]
+        trajectory = list(explore.get(instr_id, []))
+        if idx >= len(beams):        # a perturbation won: fake a wrong destination by stopping at the initial location
+            trajectory = [beams[0][0]]
+        else:
+            trajectory += beams[idx]
+        output.append({"instr_id": instr_id, "trajectory": trajectory})
+    return output
