@@ -138,3 +138,30 @@ def test_model_refuses_cpu_inputs():
     batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(*U.get_model_input(batch))
+
+
+def test_convert_scores_and_instr_ids():
+    """test.py:169-202: best-scored beam per instruction; a winning perturbation (index past the beams) stops at the start."""
+    import torch
+    from ytvln import utils_init as U
+    batch = [None] * 16
+    batch[12] = torch.tensor([[17, 0], [17, 2]])
+    assert U.get_instr_ids(batch) == ["17_0", "17_2"]
+    beams = [{"instr_id": "17_0", "ranked_paths": [["a", "b"], ["a", "c"]], "exploration_path": ["x"]},
+             {"instr_id": "17_2", "ranked_paths": [["d", "e"], ["d", "f"]], "exploration_path": ["y", "z"]}]
+    scores = [("17_0", [0.1, 0.9, float("-inf")]), ("17_2", [0.2, 0.1, 0.7])]
+    out = U.convert_scores(scores, beams)
+    assert out == [{"instr_id": "17_0", "trajectory": ["a", "c"]}, {"instr_id": "17_2", "trajectory": ["d"]}]
+    out = U.convert_scores(scores, beams, add_exploration_path=True)
+    assert out[0]["trajectory"] == [["x"], "a", "c"] and out[1]["trajectory"] == ["d"]
+
+
+def test_head_row_selection_is_static_and_ordered():
+    """Loss-aware heads: capacity is a whole number of 128-row tiles (never above the row count); flagged rows come first, in order."""
+    import torch
+    from ytvln import ops
+    from ytvln import utils_init as U
+    assert U._head_capacity(4480, 0.25) == 1152 and U._head_capacity(90, 0.25) == 90 and U._head_capacity(16128, 0.01) == 256
+    flag = torch.tensor([0, 1, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
+    assert ops.select_rows(flag, 4).tolist() == [1, 3, 4, 7]
+    assert ops.select_rows(flag, 6).tolist()[:4] == [1, 3, 4, 7]          # the tail holds un-flagged rows (ignored targets)
