@@ -488,3 +488,58 @@ def test_inference_rerank_shapes_match_oracle(dev, lib):
     for row, o in zip(ref, out):
         best = int(torch.argmax(row))
         assert o["trajectory"] == [["e0"], ["e1"]] + beam_data[0 if o["instr_id"] == "4051_0" else 1]["ranked_paths"][best]
+
+
+def test_cfg2_full_size_parity_and_properties(dev, lib):
+    """BASELINE configs[1] at its FULL per-GPU size (bs = 8 items x 7 options = 56 pairs, T = 80, R = 288, 250 M parameters):
+      * the four losses against the CPU oracle run on this box (forward only, eval-free: dropout off), |diff| <= 1e-4;
+      * size-independent properties of the path at that size:
+          - item-permutation equivariance: permuting the items permutes the ranking scores and leaves every loss unchanged
+            (rows are independent through the model, SURVEY.md 8e);
+          - masked-region invariance: features / boxes of regions whose image_mask is 0 never reach a loss
+            (they are only keys behind a -10000 additive mask; vilbert.py:295-297)."""
+    import vilbert_ref as O
+    from ytvln import synth
+    from ytvln import utils_init as U
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    model, W = build_lily(dev, "bert_base_6_layer_6_connect.json", args, seed=41)
+    model.train()                                     # dropout probabilities are zero in this configuration (ZERO_DROP)
+    nb = synth.make_batch(bs=8, K=7, T=80, frames=8, boxes=36, seed=51, ignore_rank_frac=0.0)
+    batch = synth.to_torch(nb, dev)
+    with torch.no_grad():
+        outputs, total, per = losses_of(model, batch, args)
+    S = {k: torch.from_numpy(v).clone() for k, v in W.items()}
+    cfgd = cfg_dict("bert_base_6_layer_6_connect.json", **ZERO_DROP)
+    flags = O.TaskFlags(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    cb = synth.to_torch(nb)
+    with torch.no_grad():
+        oout = O.lily_forward(S, O.RefConfig(**cfgd), flags, *O.model_input(cb))
+        ototal, oper = O.total_loss(cb, oout, flags)
+    for k, v in oper.items():
+        assert abs(float(per[k]) - float(v)) <= LOSS_TOL, (k, float(per[k]), float(v))
+    assert abs(float(total) - float(ototal)) <= 4 * LOSS_TOL
+    close(outputs["ranking"], oout["ranking"], 1e-4, 1e-4, "ranking scores at full size")
+
+    # item permutation
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev)
+    pb = [t[perm] if (torch.is_tensor(t) and t.dim() >= 1 and t.shape[0] == 8) else t for t in batch]
+    with torch.no_grad():
+        pout, ptotal, pper = losses_of(model, pb, args)
+    assert float((pout["ranking"].view(8, 7) - outputs["ranking"].view(8, 7)[perm]).abs().max()) < 2e-5
+    for k in per:
+        if not k.startswith("correct_"):
+            assert abs(float(pper[k]) - float(per[k])) < 2e-5, k
+
+    # masked regions carry no information
+    mb = list(batch)
+    dead = (batch[3] == 0)
+    feats, boxes = batch[1].clone(), batch[2].clone()
+    feats[dead] = 7.5
+    boxes[dead] = 0.25
+    boxes[..., 11] = batch[2][..., 11]               # the frame index must stay a valid embedding row
+    mb[1], mb[2] = feats, boxes
+    with torch.no_grad():
+        mout, mtotal, mper = losses_of(model, mb, args)
+    for k in per:
+        if not k.startswith("correct_"):
+            assert abs(float(mper[k]) - float(per[k])) < 2e-5, (k, float(mper[k]), float(per[k]))
