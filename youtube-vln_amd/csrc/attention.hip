@@ -257,21 +257,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 // delta[n,h,q] = sum_c dctx[n,q,h*d+c] * ctx[n,q,h*d+c]
+// LG lanes (a power of two >= d/4) share one (row, head) segment: every lane moves one 16-byte piece of ctx and dctx, so a wave
+// sweeps 1 KiB of each row contiguously; the segment sum is a log2(LG)-step shuffle reduction (fixed order -> deterministic).
+template <int LG>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ ctx, const float* __restrict__ dctx, int64_t ldo,
                                                          float* __restrict__ delta, int N, int heads, int Tq, int d) {
     const int64_t total = (int64_t)N * Tq * heads;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int sub = threadIdx.x % LG;
+    const int d4 = d >> 2;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG; i < total; i += (int64_t)gridDim.x * (256 / LG)) {
         const int h = (int)(i % heads);
         const int64_t row = i / heads;   // n*Tq + q
-        const float4* o = reinterpret_cast<const float4*>(ctx + row * ldo + h * d);
-        const float4* g = reinterpret_cast<const float4*>(dctx + row * ldo + h * d);
         float acc = 0.f;
-        for (int c = 0; c < d / 4; ++c) {
-            const float4 x = o[c], y = g[c];
-            acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        if (sub < d4) {
+            const float4 x = reinterpret_cast<const float4*>(ctx + row * ldo + h * d)[sub];
+            const float4 y = reinterpret_cast<const float4*>(dctx + row * ldo + h * d)[sub];
+            acc = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
         }
-        const int64_t nn = row / Tq, q = row % Tq;
-        delta[(nn * heads + h) * Tq + q] = acc;
+#pragma unroll
+        for (int o = LG / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (sub == 0) {
+            const int64_t nn = row / Tq, q = row % Tq;
+            delta[(nn * heads + h) * Tq + q] = acc;
+        }
     }
 }
 
@@ -522,8 +530,21 @@ extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, i
     YT_REQUIRE((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0, "attn_bwd: misaligned pointer");
     hipStream_t s = as_stream(stream);
     const int64_t total = (int64_t)N * Tq * heads;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, s, ctx, dctx, ldo,
-                       delta, N, heads, Tq, d);
+    {
+        const int d4 = d / 4;
+        const int lg = d4 <= 1 ? 1 : d4 <= 2 ? 2 : d4 <= 4 ? 4 : d4 <= 8 ? 8 : d4 <= 16 ? 16 : 32;
+        const dim3 dgrid((unsigned)std::min<int64_t>(cdiv(total * lg, 256), 8192));
+#define YT_DELTA(L) hipLaunchKernelGGL(attn_delta_kernel<L>, dgrid, dim3(256), 0, s, ctx, dctx, ldo, delta, N, heads, Tq, d)
+        switch (lg) {
+            case 1: YT_DELTA(1); break;
+            case 2: YT_DELTA(2); break;
+            case 4: YT_DELTA(4); break;
+            case 8: YT_DELTA(8); break;
+            case 16: YT_DELTA(16); break;
+            default: YT_DELTA(32); break;
+        }
+#undef YT_DELTA
+    }
     {
         const int nw = pick_waves(Tq);
         dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
