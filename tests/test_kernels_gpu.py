@@ -282,7 +282,7 @@ def ref_attention(q, k, v, mask, heads, dropmask=None, p=0.0):
 
 @pytest.mark.parametrize("N,heads,d,Tq,Tk", [(2, 4, 8, 8, 6), (2, 4, 12, 6, 6), (3, 4, 64, 80, 80), (2, 8, 128, 288, 288),
                                              (2, 8, 128, 80, 288), (2, 8, 128, 288, 80), (2, 2, 64, 16, 8), (1, 2, 128, 252, 100),
-                                             (1, 3, 32, 33, 65)])
+                                             (1, 3, 32, 33, 65), (1, 2, 64, 1000, 808), (1, 1, 128, 1, 3), (1, 2, 64, 512, 512)])
 def test_attention_fwd_bwd(dev, lib, N, heads, d, Tq, Tk):
     from ytvln import ops
     H = heads * d
@@ -562,3 +562,30 @@ def test_gemm_bf16_staged(dev, lib, M, N, K, ta, tb, epi):
     full = (A.t() if ta else A).double().cpu() @ (B if tb else B.t()).double().cpu().t() + bias.double().cpu()
     if not epi:
         assert float((C.double().cpu() - full).abs().max()) > 1e-3
+
+
+def test_edge_cases_and_loud_failures(dev, lib):
+    """Empty problems are no-ops; illegal arguments raise with the library's message (no silent fallback of any kind)."""
+    from ytvln import ops
+    from ytvln._lib import call
+    A = torch.randn(8, 16, device=dev)
+    C = torch.full((4, 4), 7.0, device=dev)
+    # M == 0 / N == 0: nothing is launched, C untouched
+    call("ytvln_gemm_f32", A.data_ptr(), 16, 0, A.data_ptr(), 16, 1, C.data_ptr(), 4, None, None, 0, 0, 4, 16, 0, 0.0, None, 0, 0, None)
+    assert float(C.min()) == 7.0
+    with pytest.raises(RuntimeError, match="leading dimension"):
+        call("ytvln_gemm_f32", A.data_ptr(), 8, 0, A.data_ptr(), 16, 1, C.data_ptr(), 4, None, None, 0, 4, 4, 16, 0, 0.0, None, 0, 0, None)
+    with pytest.raises(RuntimeError, match="epilogue"):
+        call("ytvln_gemm_f32", A.data_ptr(), 16, 0, A.data_ptr(), 16, 1, C.data_ptr(), 4, None, None, 0, 4, 4, 16, 9, 0.0, None, 0, 0, None)
+    with pytest.raises(RuntimeError, match="head dim"):
+        ops._attn_fwd(A, 0, 16, A, 0, 16, A, 0, 16, None, torch.empty(8, 16, device=dev), 1, 1, 8, 8, 6, 1.0, 0.0, None, 0)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.linear(torch.randn(4, 16), torch.randn(8, 16, device=dev))
+    with pytest.raises(RuntimeError, match="float32"):
+        ops.linear(torch.randn(4, 16, device=dev, dtype=torch.float64), torch.randn(8, 16, device=dev))
+    with pytest.raises(RuntimeError, match="multiple of 64|rounded up to 64"):
+        call("ytvln_cast_bf16", A.data_ptr(), 16, 8, 16, 0, C.data_ptr(), 16, None)
+    # empty row sets through the row kernels
+    out = torch.empty(0, 16, device=dev)
+    call("ytvln_gather_rows_f32", A.data_ptr(), 16, None, 0, 16, out.data_ptr(), None)
+    assert ops.select_rows(torch.zeros(5, dtype=torch.bool, device=dev), 3).tolist() == [0, 1, 2]
