@@ -89,6 +89,19 @@ int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
                        float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
                        int64_t workspace_elems, void* stream);
 
+/* On-device batch preparation: the masking the reference applies per item on the host.
+ *   ytvln_randomize_tokens  = randomize_tokens (utils/dataset/common.py:213-270, mask_action_rate = 0):  p = U[0,1) * mask;
+ *     p >= 0.85: target = token, token = [MASK];  p >= 0.97: token = random id;  p >= 0.985: token = original;  targets -1 elsewhere.
+ *   ytvln_randomize_regions = randomize_regions (common.py:272-300):  p >= 0.85: targets = probs, targets_mask = 1 (else 1/C, 0);
+ *     p >= 0.865: the feature row is zeroed IN PLACE.
+ *   Draws: explicit (`p`, `random_tokens`; pins the kernels bit-for-bit to the reference functions) or, when those are NULL, the
+ *   Philox stream keyed by the device-resident (seed, counter) pair `rng` and `site` (the same state as the dropout kernels). */
+int ytvln_randomize_tokens(const int64_t* tokens, const int64_t* mask, int64_t n, int vocab_size, int64_t mask_token_id,
+                           const float* p, const int64_t* random_tokens, const int64_t* rng, int64_t site,
+                           int64_t* tokens_out, int64_t* targets_out, void* stream);
+int ytvln_randomize_regions(float* features, int64_t ldf, const float* probs, const int64_t* mask, int64_t rows, int F, int C,
+                            const float* p, const int64_t* rng, int64_t site, float* targets, int64_t* targets_mask, void* stream);
+
 /* out[j, :] = x[idx[j], :] (zeros where idx[j] < 0): row gather in front of the loss-aware prediction heads (only rows that
  * carry a masked-language / masked-vision target are decoded; "next" row of SURVEY.md section 8f).  Backward =
  * ytvln_scatter_add_rows_f32 with skip_idx = -1. */

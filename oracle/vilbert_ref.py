@@ -489,3 +489,36 @@ def train_step(S: State, cfg: RefConfig, flags: TaskFlags, batch, st: AdamWState
     if "cls.predictions.decoder.weight" in S:
         S["cls.predictions.decoder.weight"] = S["bert.embeddings.word_embeddings.weight"]
     return loss.detach(), {k: v.detach() for k, v in per_task.items()}, grads, out
+
+
+# --------------------------------------------------------------------------------------
+# batch preparation on the host side of the reference (utils/dataset/common.py:213-300), restated with the uniform draws as
+# explicit inputs so that the HIP kernels (csrc/batch.hip) can be pinned bit-for-bit
+# --------------------------------------------------------------------------------------
+def randomize_tokens(tokens: Tensor, mask: Tensor, p_raw: Tensor, random_tokens: Tensor, mask_token_id: int = 103):
+    """common.py:213-270 with mask_action_rate == 0.  p_raw = torch.rand_like(tokens.float()); returns (tokens, targets)."""
+    tokens = tokens.clone()
+    targets = torch.ones_like(tokens) * -1
+    p = p_raw * mask.float()
+    thresh = 0.85
+    targets[p >= thresh] = tokens[p >= thresh]
+    tokens[p >= thresh] = mask_token_id                     # 80 %: [MASK]
+    thresh = 0.85 + 0.15 * 0.8
+    tokens[p >= thresh] = random_tokens[p >= thresh]        # 10 %: random word
+    thresh = 0.85 + 0.15 * 0.9
+    tokens[p >= thresh] = targets[p >= thresh]              # 10 %: unchanged
+    return tokens, targets
+
+
+def randomize_regions(features: Tensor, probs: Tensor, mask: Tensor, p_raw: Tensor):
+    """common.py:272-300.  p_raw = torch.rand_like(mask.float()); returns (features, targets, targets_mask)."""
+    features = features.clone()
+    targets = torch.ones_like(probs) / probs.shape[-1]
+    targets_mask = torch.zeros_like(mask)
+    p = p_raw * mask.float()
+    thresh = 0.85
+    targets[p >= thresh] = probs[p >= thresh]
+    targets_mask[p >= thresh] = 1
+    thresh = 0.85 + 0.15 * 0.1
+    features[p >= thresh] = 0
+    return features, targets, targets_mask

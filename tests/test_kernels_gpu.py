@@ -589,3 +589,92 @@ def test_edge_cases_and_loud_failures(dev, lib):
     out = torch.empty(0, 16, device=dev)
     call("ytvln_gather_rows_f32", A.data_ptr(), 16, None, 0, 16, out.data_ptr(), None)
     assert ops.select_rows(torch.zeros(5, dtype=torch.bool, device=dev), 3).tolist() == [0, 1, 2]
+
+
+def test_batch_masking_matches_reference_golden(dev, lib):
+    """csrc/batch.hip with explicit draws == the reference's randomize_tokens / randomize_regions, bit for bit (integers and fp32
+    copies / zeros), on the fixture generated by running the reference (tests/golden/g7_masking.npz)."""
+    from helpers import gold
+    from ytvln import batch as B
+    g = gold("g7_masking.npz")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)   # noqa: E731
+    tok, tgt = B.randomize_tokens(t("tokens"), t("mask"), p=t("p_tok"), random_tokens=t("rnd_tok"))
+    assert torch.equal(tok, t("out_tok")) and torch.equal(tgt, t("tgt_tok"))
+    feats = t("feats").clone()
+    f, tg, m = B.randomize_regions(feats, t("probs"), t("rmask"), p=t("p_reg"))
+    assert f.data_ptr() == feats.data_ptr()                      # in place, like the reference
+    assert torch.equal(f, t("out_f")) and torch.equal(tg, t("out_t")) and torch.equal(m, t("out_m"))
+
+
+def test_batch_masking_philox_statistics(dev, lib):
+    """Production mode (Philox draws) at the BASELINE config-2 batch size: the masking rates of common.py:213-300 within 4 sigma,
+    structural invariants exactly, a fresh mask on every call."""
+    from ytvln import batch as B, synth
+    nb = synth.make_batch(bs=8, K=7, T=80, frames=8, boxes=36, seed=3, ignore_rank_frac=0.0)
+    bt = synth.to_torch(nb, dev)
+    tokens, imask = bt[6].clone(), bt[7]
+    orig = torch.where(bt[8] != -1, bt[8], tokens)               # undo the generator's own masking: start from clean tokens
+    out, tgt = B.randomize_tokens(orig, imask)
+    valid = imask.bool()
+    sel = tgt != -1
+    n = int(valid.sum())
+    assert not bool(sel[~valid].any())                           # padding is never a target
+    assert torch.equal(tgt[sel], orig[sel])                      # targets hold the original ids
+    rate = float(sel.sum()) / n
+    assert abs(rate - 0.15) < 4 * (0.15 * 0.85 / n) ** 0.5, rate
+    frac_mask = float((out[sel] == 103).sum()) / int(sel.sum())
+    frac_keep = float((out[sel] == orig[sel]).sum()) / int(sel.sum())
+    ns = int(sel.sum())
+    assert abs(frac_mask - 0.8) < 4 * (0.16 / ns) ** 0.5 and abs(frac_keep - 0.1) < 4 * (0.09 / ns) ** 0.5 + 1e-3, (frac_mask, frac_keep)
+    assert torch.equal(out[~sel], orig[~sel])
+    out2, tgt2 = B.randomize_tokens(orig, imask)
+    assert not torch.equal(tgt, tgt2)                            # the device-side counter advanced
+    feats = torch.relu(torch.randn(56, 288, 2048, device=dev))
+    probs = torch.softmax(torch.randn(56, 288, 1601, device=dev), -1)
+    keep = feats.clone()
+    rmask = bt[3].reshape(56, 288)
+    f, targets, tm = B.randomize_regions(feats, probs, rmask)
+    rv = rmask.bool()
+    assert not bool(tm[~rv].any())
+    r = float(tm.sum()) / int(rv.sum())
+    assert abs(r - 0.15) < 4 * (0.15 * 0.85 / int(rv.sum())) ** 0.5, r
+    s = tm.bool()
+    assert torch.equal(targets[s], probs[s]) and bool((targets[~s] == 1.0 / 1601).all())
+    zeroed = (f.abs().sum(-1) == 0) & (keep.abs().sum(-1) != 0)
+    assert not bool((zeroed & ~s).any())                         # only selected regions are zeroed
+    zf = float(zeroed.sum()) / int(s.sum())
+    assert abs(zf - 0.9) < 4 * (0.09 / int(s.sum())) ** 0.5, zf
+    assert torch.equal(f[~zeroed], keep[~zeroed])
+
+
+def test_expand_options_matches_host_expansion(dev, lib):
+    """ytvln.batch.expand_options == materialising the K options on the host the way the reference's dataset does (positive path,
+    shared-feature caption negatives, frame permutations, frames swapped for other photos, padded frames)."""
+    from ytvln import batch as B
+    g = torch.Generator().manual_seed(5)
+    P, boxes, F, C, bs, K, frames = 23, 6, 64, 21, 3, 7, 4
+    pf = torch.relu(torch.randn(P, boxes, F, generator=g))
+    pb = torch.rand(P, boxes, 12, generator=g)
+    pp = torch.softmax(torch.randn(P, boxes, C, generator=g), -1)
+    pm = (torch.rand(P, boxes, generator=g) < 0.8).long()
+    index = torch.full((bs, K, frames), -1, dtype=torch.int64)
+    for b in range(bs):
+        L = 2 + b % 3                                             # path length (the rest is padding)
+        path = torch.randperm(P, generator=g)[:L]
+        index[b, 0, :L] = index[b, 1, :L] = index[b, 2, :L] = path            # positive + two caption negatives share the frames
+        index[b, 3, :L] = path[torch.randperm(L, generator=g)]                  # frame permutations
+        index[b, 4, :L] = path[torch.randperm(L, generator=g)]
+        for k in (5, 6):                                                        # some frames swapped for random photos
+            alt = path.clone()
+            alt[int(torch.randint(0, L, (1,), generator=g))] = int(torch.randint(0, P, (1,), generator=g))
+            index[b, k, :L] = alt
+    f, bx, pr, m = B.expand_options(pf.to(dev), pb.to(dev), pp.to(dev), pm.to(dev), index.to(dev))
+    safe = index.clamp(min=0)
+    valid = (index >= 0)
+    ef = (pf[safe] * valid[..., None, None]).reshape(bs, K, frames * boxes, F)
+    eb = pb[safe] * valid[..., None, None]
+    eb[..., 11] = torch.arange(frames).view(1, 1, frames, 1) * valid[..., None]
+    ep = (pp[safe] * valid[..., None, None]).reshape(bs, K, frames * boxes, C)
+    em = (pm[safe] * valid[..., None]).reshape(bs, K, frames * boxes)
+    assert torch.equal(f.cpu(), ef) and torch.equal(bx.cpu(), eb.reshape(bs, K, frames * boxes, 12))
+    assert torch.equal(pr.cpu(), ep) and torch.equal(m.cpu(), em)

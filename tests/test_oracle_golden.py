@@ -144,3 +144,17 @@ def test_encoder_schedule_matches_survey():
     assert order == "T0,T1,T2,T3,T4,T5,C0,V0,T6,C1,V1,T7,C2,V2,T8,C3,V3,T9,C4,V4,T10,C5,V5,T11,"
     tiny = O.RefConfig(**cfg_dict("tiny_2_2_1.json"))
     assert "".join(f"{k.upper()}{i}," for k, i in O.encoder_schedule(tiny)) == "V0,T0,C0,V1,T1,"
+
+
+def test_g7_masking_restatement_matches_reference():
+    """oracle.randomize_tokens / randomize_regions against the outputs of the reference's functions (utils/dataset/common.py:213-300)
+    on the same inputs and the same uniform draws (oracle/gen_golden_masking.py)."""
+    g = gold("g7_masking.npz")
+    t = lambda k: torch.from_numpy(g[k])   # noqa: E731
+    tok, tgt = O.randomize_tokens(t("tokens"), t("mask"), t("p_tok"), t("rnd_tok"))
+    assert torch.equal(tok, t("out_tok")) and torch.equal(tgt, t("tgt_tok"))
+    f, tg, m = O.randomize_regions(t("feats"), t("probs"), t("rmask"), t("p_reg"))
+    assert torch.equal(f, t("out_f")) and torch.equal(tg, t("out_t")) and torch.equal(m, t("out_m"))
+    # the fixture exercises every branch
+    p = t("p_tok") * t("mask").float()
+    assert int(((p >= 0.85) & (p < 0.97)).sum()) > 0 and int(((p >= 0.97) & (p < 0.985)).sum()) > 0 and int((p >= 0.985).sum()) > 0

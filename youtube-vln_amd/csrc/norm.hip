@@ -285,21 +285,29 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 
 // out[j, :] = x[idx[j], :]   (idx < 0 -> zeros).  Row gather for the loss-aware heads (only rows carrying a target go through
 // the 30522-way / 1601-way decoders); its backward is scatter_add_rows_kernel.
+// Work unit = one 1024-float piece of one output row (a wave moves it as 4 x 16 bytes per lane), so short rows (hidden states in front
+// of the loss-aware heads) and very long ones (a whole frame of 36 x 2048-d region features, ytvln.batch.expand_options) both spread
+// over the chip.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ idx,
                                                           int R, int H, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+    const int ppr = (H + 1023) >> 10;                       // pieces per row
+    const int64_t pieces = (int64_t)R * ppr;
+    for (int64_t pc = (int64_t)blockIdx.x * 4 + wave; pc < pieces; pc += (int64_t)gridDim.x * 4) {
+        const int r = (int)(pc / ppr), c0 = (int)(pc % ppr) << 10;
         const int64_t k = idx[r];
+        const float* src = x + (k < 0 ? 0 : k) * ldx;
+        float* dst = out + (int64_t)r * H;
         if (VEC) {
-            const int H4 = H >> 2;
-            float4* dst = reinterpret_cast<float4*>(out + (int64_t)r * H);
-            const float4* src = reinterpret_cast<const float4*>(x + (k < 0 ? 0 : k) * ldx);
-            for (int c = lane; c < H4; c += 64) dst[c] = k < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : src[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 4 * (lane + 64 * u);
+                if (c < H)
+                    *reinterpret_cast<float4*>(dst + c) = k < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(src + c);
+            }
         } else {
-            float* dst = out + (int64_t)r * H;
-            const float* src = x + (k < 0 ? 0 : k) * ldx;
-            for (int c = lane; c < H; c += 64) dst[c] = k < 0 ? 0.f : src[c];
+            for (int c = c0 + lane; c < min(c0 + 1024, H); c += 64) dst[c] = k < 0 ? 0.f : src[c];
         }
     }
 }
@@ -478,7 +486,7 @@ extern "C" int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int
 extern "C" int ytvln_gather_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int R, int H, float* out, void* stream) {
     if (R == 0) return 0;
     YT_REQUIRE(x && idx && out && R > 0 && H > 0 && ldx >= H, "gather_rows: bad argument");
-    const dim3 grid((unsigned)std::min<int64_t>(cdiv(R, 4), 4096));
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv((int64_t)R * cdiv(H, 1024), 4), 16384));
     if (H % 4 == 0 && ldx % 4 == 0 && al16(x) && al16(out))
         hipLaunchKernelGGL(gather_rows_kernel<true>, grid, dim3(256), 0, as_stream(stream), x, ldx, idx, R, H, out);
     else

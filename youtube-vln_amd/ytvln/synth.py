@@ -135,6 +135,54 @@ def make_batch(bs: int, K: int, T: int, frames: int, boxes: int, F: int = 2048, 
             np.arange(bs, dtype=np.int64), opt_mask, np.zeros(bs, np.int64), np.zeros(bs, np.int64)]
 
 
+def make_pool(bs: int, K: int, T: int, frames: int, boxes: int, F: int = 2048, C: int = 1601, vocab: int = 30522, seed: int = 1234):
+    """The same kind of batch in the COMPACT form consumed by ytvln.batch (on-device assembly): every distinct frame once
+    (`pool_*`, one entry per frame) + `index [bs, K, frames]` saying which pool frame each option shows at each position (-1 = padding)
+    + un-masked tokens.  Option structure as in make_batch: 0 positive, 1-2 caption negatives sharing its frames, 3-4 frame
+    permutations, 5-6 some frames swapped for other photos.  Returns (pool_features, pool_boxes, pool_probs, pool_masks, index,
+    tokens [bs,K,T], instr_mask [bs,K,T])."""
+    rs = np.random.RandomState(seed)
+    per_item = frames + 2 * (frames // 2)                     # the path + replacement photos for the two "random" negatives
+    P = bs * per_item
+    pf = np.maximum(rs.standard_normal((P, boxes, F)).astype(np.float32), 0.0)
+    pb = np.ones((P, boxes, 12), np.float32)
+    xy = np.sort(rs.uniform(0, 1, (P, boxes, 2, 2)).astype(np.float32), axis=-1)
+    pb[..., 0], pb[..., 2], pb[..., 1], pb[..., 3] = xy[..., 0, 0], xy[..., 0, 1], xy[..., 1, 0], xy[..., 1, 1]
+    pb[..., 4] = (pb[..., 2] - pb[..., 0]) * (pb[..., 3] - pb[..., 1])
+    nb = rs.randint(min(10, boxes), boxes + 1, size=P)
+    pm = (np.arange(boxes)[None, :] < nb[:, None]).astype(np.int64)
+    pf[:, 0] = (pf * pm[..., None]).sum(1) / np.maximum(pm.sum(1, keepdims=True), 1)
+    pb[:, 0, :5] = np.array([0, 0, 1, 1, 1], np.float32)
+    logits = (rs.standard_normal((P, boxes, C)) * 3.0).astype(np.float32)
+    logits -= logits.max(-1, keepdims=True)
+    pp = np.exp(logits)
+    pp /= pp.sum(-1, keepdims=True)
+    index = np.full((bs, K, frames), -1, np.int64)
+    tokens = np.zeros((bs, K, T), np.int64)
+    for i in range(bs):
+        base = i * per_item
+        L = rs.randint(min(4, frames), frames + 1)
+        path = base + np.arange(L)
+        spare = base + frames + np.arange(2 * (frames // 2))
+        ins = []
+        for _ in range(3):
+            n = rs.randint(min(20, T - 2), T - 1)
+            t = np.zeros(T, np.int64)
+            t[0], t[1:1 + n], t[1 + n] = 101, rs.randint(1000, vocab, size=n), 102
+            ins.append(t)
+        for k in range(K):
+            row = path.copy()
+            if k in (3, 4):
+                row = path[rs.permutation(L)]
+            elif k >= 5:
+                sw = np.nonzero(rs.rand(L) < 0.5)[0]
+                sw = sw[sw > 0][:frames // 2]
+                row[sw] = spare[(k - 5) * (frames // 2):(k - 5) * (frames // 2) + len(sw)]
+            index[i, k, :L] = row
+            tokens[i, k] = ins[k] if k in (1, 2) else ins[0]
+    return pf, pb, pp.astype(np.float32), pm, index, tokens, (tokens > 0).astype(np.int64)
+
+
 def to_torch(batch: List[np.ndarray], device="cpu"):
     import torch
     return [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in batch]
