@@ -474,10 +474,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// split-K plan: only for plain (no activation) GEMMs whose 128x128 tiling cannot fill the chip.  256 CUs hold 512 resident
-// 128x128 workgroups; pick the split count whose tiles x splits best fills whole rounds of 512 (fewest splits on ties), with
-// at least 8 k-tiles per split.
-static int plan_splits(int M, int N, int K, int epilogue) {
+// Launch plan = (tile shape, split count), chosen by a small cost model fitted to measurements on MI355X:
+//  * a CU delivers about the same GEMM throughput with one or two resident 128x128 workgroups (0.46 vs 0.49 TFLOP/s), so what a
+//    launch pays for is the number of block "waves" ceil(blocks / 256 CUs), not rounds of the 512 resident slots;
+//  * per block: a fixed cost (prologue DMA round trip + epilogue) plus k-tiles at the CU-exclusive rate of the tile shape
+//    (128x128 / 8 waves: 2.14 us per 32-deep k-tile; 128x64 and 64x64 / 4 waves: 1.2 and 0.61 us -- ~12 % less efficient);
+//  * split-K (plain epilogues only, 128x128 tiles) adds the workspace round trip and the reduce launch.
+struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64
+
+static double plan_cost(int M, int N, int K, int tile, int sp) {
+    static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+    static const double tk[3] = {2.14, 1.20, 0.61}, tfix[3] = {5.0, 3.0, 3.0};
+    const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
+    const int splits = (int)cdiv(K, kchunk);
+    const double blocks = (double)(cdiv(M, bm[tile]) * cdiv(N, bn[tile])) * splits;
+    const double waves = ceil(blocks / 256.0);
+    double t = waves * (tfix[tile] + (double)(kchunk / BK) * tk[tile]);
+    if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / 3.0e6;     // us: launch + bytes at ~3 TB/s
+    return t;
+}
+
+static Plan plan_gemm(int M, int N, int K, int epilogue) {
+    Plan best = {0, 1};
+    double best_t = 1e30;
+    const int force_tile = getenv("YTVLN_GEMM_TILE") ? atoi(getenv("YTVLN_GEMM_TILE")) : -1;       // experiment knobs
+    const int force_sp = getenv("YTVLN_GEMM_SPLITS") ? atoi(getenv("YTVLN_GEMM_SPLITS")) : -1;
+    for (int tile = 0; tile < 3; ++tile) {
+        if (force_tile >= 0 && tile != force_tile) continue;
+        const int smax = (tile == 0 && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
+        for (int sp = 1; sp <= std::max(1, smax); ++sp) {
+            if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
+            const double t = plan_cost(M, N, K, tile, sp);
+            if (t < best_t * 0.98) { best_t = t; best = {tile, sp}; }       // fewer splits / larger tiles win near-ties
+        }
+    }
+    return best;
+}
+
+static int plan_splits(int M, int N, int K, int epilogue) { return plan_gemm(M, N, K, epilogue).splits; }
+
+// bf16 launches (K counted in 4-byte words): matrix time is 8x shorter, so the legacy occupancy rule (fill whole rounds of the 512
+// resident workgroups, at least 8 k-tiles per split) is kept for them.
+static int plan_splits_bf16(int M, int N, int K, int epilogue) {
     if (epilogue != YTVLN_EPI_NONE) return 1;
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
     if (tiles >= 384 || K < 1024) return 1;
@@ -613,7 +651,7 @@ static void launch_bf16(GemmArgs& g, hipStream_t s) {
 using namespace ytvln;
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
-    const int splits = plan_splits(M, N, K, epilogue);
+    const int splits = std::max(plan_splits(M, N, K, epilogue), plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points
     return splits > 1 ? (int64_t)splits * M * N : 0;
 }
 
@@ -646,11 +684,19 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
     g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
              !getenv("YTVLN_GEMM_GENERIC");
-    const int want = plan_splits(M, N, K, epilogue);
+    Plan plan = plan_gemm(M, N, K, epilogue);
+    const int want = plan.splits;
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
         g.splits = (int)cdiv(K, g.kchunk);
         g.ws = workspace;
+    } else if (want > 1) {                 // no workspace supplied: best unsplit plan
+        plan.splits = 1;
+        double bt = 1e30;
+        for (int tile = 0; tile < 3; ++tile) {
+            const double t = plan_cost(M, N, K, tile, 1);
+            if (t < bt * 0.98) { bt = t; plan.tile = tile; }
+        }
     }
     if (g.splits == 1) g.kchunk = std::max(g.kchunk, g.Kloop);
     if (g.splits > 1) {
@@ -660,10 +706,8 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
                            ldc, bias, M, N, g.splits, beta);
     } else {
         g.splits = 1;
-        // tile choice: the largest tile that still gives >= ~1.5 workgroups per CU (256 CUs, 2 resident 128x128 blocks/CU)
-        const int64_t b128 = cdiv(M, 128) * cdiv(N, 128), b12864 = cdiv(M, 128) * cdiv(N, 64);
-        if (b128 >= 384) launch_tile<128, 128>(g, transA, transB, s);
-        else if (b12864 >= 384) launch_tile<128, 64>(g, transA, transB, s);
+        if (plan.tile == 0) launch_tile<128, 128>(g, transA, transB, s);
+        else if (plan.tile == 1) launch_tile<128, 64>(g, transA, transB, s);
         else launch_tile<64, 64>(g, transA, transB, s);
     }
     YT_LAUNCH_CHECK("gemm_f32");
@@ -705,7 +749,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
     g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
-    const int want = plan_splits(M, N, K / 2, epilogue);
+    const int want = plan_splits_bf16(M, N, K / 2, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(g.Kloop, want), BK) * BK;
         g.splits = (int)cdiv(g.Kloop, g.kchunk);
