@@ -478,18 +478,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //  * a CU delivers about the same GEMM throughput with one or two resident 128x128 workgroups (0.46 vs 0.49 TFLOP/s), so what a
 //    launch pays for is the number of block "waves" ceil(blocks / 256 CUs), not rounds of the 512 resident slots;
 //  * per block: a fixed cost (prologue DMA round trip + epilogue) plus k-tiles at the CU-exclusive rate of the tile shape
-//    (128x128 / 8 waves: 2.14 us per 32-deep k-tile; 128x64 and 64x64 / 4 waves: 1.2 and 0.61 us -- ~12 % less efficient);
+//    (128x128 / 8 waves: 2.14 us per 32-deep k-tile; 128x64 and 64x64 / 4 waves: 1.14 and 0.55 us);
 //  * split-K (plain epilogues only, 128x128 tiles) adds the workspace round trip and the reduce launch.
 struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64
 
 static double plan_cost(int M, int N, int K, int tile, int sp) {
     static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-    static const double tk[3] = {2.14, 1.20, 0.61}, tfix[3] = {5.0, 3.0, 3.0};
+    static const double tk[3] = {2.14, 1.14, 0.55}, tfix[3] = {5.0, 3.0, 3.0};
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
     const int splits = (int)cdiv(K, kchunk);
     const double blocks = (double)(cdiv(M, bm[tile]) * cdiv(N, bn[tile])) * splits;
     const double waves = ceil(blocks / 256.0);
-    double t = waves * (tfix[tile] + (double)(kchunk / BK) * tk[tile]);
+    // the 4-wave tiles only reach their rate with 2-3 blocks co-resident on a CU (one block = one wave per SIMD)
+    const double need = tile == 0 ? 1.0 : tile == 1 ? 2.0 : 3.0, per_cu = std::max(1.0, blocks / 256.0);
+    const double occ = per_cu < need ? need / per_cu : 1.0;
+    double t = waves * (tfix[tile] + (double)(kchunk / BK) * tk[tile] * occ);
     if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / 3.0e6;     // us: launch + bytes at ~3 TB/s
     return t;
 }
