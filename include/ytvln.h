@@ -162,6 +162,18 @@ int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
                        int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng, int64_t site,
                        void* stream);
 
+/* bf16-operand variants of the two attention entry points (opt-in bf16 MFMA path, BASELINE config 5): identical arguments, layouts and
+ * fp32 tensors; inside the kernels the QK^T, PV and gradient contractions run on v_mfma_f32_32x32x16_bf16 with the operands rounded to
+ * bf16 on the way from LDS / registers, fp32 accumulation, fp32 softmax.  Head dim must be a multiple of 8. */
+int ytvln_attn_fwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                        const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                        int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream);
+int ytvln_attn_bwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                        const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
+                        float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                        int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
+                        int64_t site, void* stream);
+
 /* probs[n,h,i,j] = exp(q_i.k_j*scale + mask - lse): the attention_probs tensor the reference returns when
  * output_all_attention_masks=True (vilbert.py:300, 311).  Diagnostic path, not on the training step. */
 int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,

@@ -678,3 +678,43 @@ def test_expand_options_matches_host_expansion(dev, lib):
     em = (pm[safe] * valid[..., None]).reshape(bs, K, frames * boxes)
     assert torch.equal(f.cpu(), ef) and torch.equal(bx.cpu(), eb.reshape(bs, K, frames * boxes, 12))
     assert torch.equal(pr.cpu(), ep) and torch.equal(m.cpu(), em)
+
+
+@pytest.mark.parametrize("N,heads,d,Tq,Tk", [(2, 8, 128, 288, 288), (2, 8, 128, 80, 288), (2, 8, 128, 288, 80), (3, 12, 64, 80, 80),
+                                             (1, 3, 32, 33, 65), (1, 2, 8, 6, 9)])
+def test_attention_bf16_operands(dev, lib, N, heads, d, Tq, Tk):
+    """bf16-operand attention (opt-in, BASELINE config 5) against the fp64 reference on the SAME fp32 inputs.  Stated tolerance for
+    this mode: relative L2 <= 1e-2 forward, <= 2e-2 for dQ / dK / dV (q, k, v, the probabilities and dS are rounded to bf16 --
+    2^-9 relative -- before each contraction; accumulation, softmax and lse stay fp32).  The result must also DIFFER from the fp32
+    kernel's (guards against a silent fp32 fallback)."""
+    from ytvln import ops
+    H = heads * d
+    A = rnd(dev, N * Tq, 3 * H, seed=1)
+    B = rnd(dev, N * Tk, 3 * H, seed=2)
+    mask = torch.zeros(N, Tk, device=dev)
+    mask[0, Tk - max(1, Tk // 4):] = -10000.0
+    scale = 1 / math.sqrt(d)
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        ops.set_matmul_precision(mode)
+        try:
+            out = torch.empty(N * Tq, H, device=dev)
+            lse = ops._attn_fwd(A, 0, 3 * H, B, H, 3 * H, B, 2 * H, 3 * H, mask, out, N, heads, Tq, Tk, d, scale, 0.0, None, 0)
+            dout = rnd(dev, N * Tq, H, seed=3)
+            gA, gB = torch.zeros_like(A), torch.zeros_like(B)
+            ops._attn_bwd(A, 0, 3 * H, B, H, 3 * H, B, 2 * H, 3 * H, mask, out, dout, lse, gA, 0, 3 * H, gB, H, 3 * H, gB, 2 * H, 3 * H,
+                          N, heads, Tq, Tk, d, scale, 0.0, None, 0)
+        finally:
+            ops.set_matmul_precision("fp32")
+        outs[mode] = (out, gA[:, :H].clone(), gB[:, H:2 * H].clone(), gB[:, 2 * H:].clone())
+    qd = A[:, :H].double().view(N, Tq, H).requires_grad_(True)
+    kd = B[:, H:2 * H].double().reshape(N, Tk, H).requires_grad_(True)
+    vd = B[:, 2 * H:].double().reshape(N, Tk, H).requires_grad_(True)
+    ref, _ = ref_attention(qd, kd, vd, mask.double(), heads)
+    ref.backward(rnd(dev, N * Tq, H, seed=3).double().view(N, Tq, H))
+    o, dq, dk, dv = outs["bf16"]
+    assert rel_l2(o.view(N, Tq, H), ref) < 1e-2, rel_l2(o.view(N, Tq, H), ref)
+    assert rel_l2(dq.reshape(N, Tq, H), qd.grad) < 2e-2, rel_l2(dq.reshape(N, Tq, H), qd.grad)
+    assert rel_l2(dk.reshape(N, Tk, H), kd.grad) < 2e-2, rel_l2(dk.reshape(N, Tk, H), kd.grad)
+    assert rel_l2(dv.reshape(N, Tk, H), vd.grad) < 2e-2, rel_l2(dv.reshape(N, Tk, H), vd.grad)
+    assert rel_l2(o, outs["fp32"][0]) > 1e-5, "bf16 attention reproduced the fp32 kernel: the bf16 path did not run"

@@ -419,7 +419,8 @@ def test_loss_aware_heads_match_full_heads(dev, lib, all_options):
 
 
 def test_g2_full_model_bf16_projections(dev, lib):
-    """BASELINE config 5's arithmetic (bf16-staged projections on v_mfma_f32_32x32x16_bf16, fp32 accumulation, everything else fp32)
+    """BASELINE config 5's arithmetic (bf16-staged projections and bf16-operand attention on v_mfma_f32_32x32x16_bf16, fp32 accumulation,
+    fp32 softmax / LayerNorm / losses / master weights)
     against the same fp32 golden as test_g2.  Stated tolerance for this mode: each loss within 2e-2 relative (bf16 has an 8-bit
     mantissa: 2^-9 = 2e-3 relative rounding per operand, averaged over the contractions and 24 layers), gradient norms within 5 %.
     The fp32 path's 1e-4 bar does not apply -- and must NOT be met bit-for-bit, which guards against a silent fp32 fallback."""
@@ -450,7 +451,8 @@ def test_g2_full_model_bf16_projections(dev, lib):
     bad = []
     for n, ref in zip(g["grad_names"].tolist(), g["grad_norms"]):
         got = float(pd[n].grad.double().norm())
-        if abs(got - ref) > 5e-2 * ref + 1e-6:
+        # (+1e-4: key-projection biases have a mathematically zero gradient -- softmax shift invariance -- so theirs is pure rounding noise)
+        if abs(got - ref) > 5e-2 * ref + 1e-4:
             bad.append((n, got, float(ref)))
     assert not bad, bad[:5]
 

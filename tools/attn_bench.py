@@ -12,6 +12,7 @@ only = os.environ.get("CASES")          # e.g. CASES="co" -> only the BertBiAtte
 if only:
     cases = [c for c in cases if c[0].startswith(only)]
 fwd_only = bool(os.environ.get("FWD_ONLY"))
+ops.set_matmul_precision(os.environ.get("PRECISION", "fp32"))      # PRECISION=bf16 -> bf16-operand kernels
 p = float(os.environ.get("PDROP", "0.1"))
 st = ops.DropoutState(dev)
 for name, h, d, Tq, Tk in cases:

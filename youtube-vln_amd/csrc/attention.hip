@@ -36,6 +36,7 @@ struct AttnArgs {
     int N, heads, Tq, Tk, d;
     float scale, p_drop;
     const int64_t* rng; int64_t site;
+    int bf16;          // 1: bf16 MFMA operands (ytvln_attn_*_bf16 entry points)
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -112,12 +113,35 @@ __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __
     }
 }
 
+// bf16-operand variants (opt-in "bf16 MFMA path", BASELINE config 5): tiles and register fragments stay fp32; eight consecutive
+// contraction values of a lane are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on the way into ONE v_mfma_f32_32x32x16_bf16 where the
+// fp32 path issues eight 32x32x2 instructions.  Accumulators, softmax, lse / delta and every stored tensor remain fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, float e, float f, float g, float h) {
+    bf16x8 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+    v[4] = (__bf16)e; v[5] = (__bf16)f; v[6] = (__bf16)g; v[7] = (__bf16)h;
+    return v;
+}
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
 // acc (32x32) = Xs-tile (rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T
-template <int DP>
+template <int DP, bool BF = false>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (BF) {
+#pragma unroll
+        for (int s8 = 0; s8 < DP / 2; s8 += 8) {       // this half-wave's contraction values s8 .. s8+7 (two 16-byte granules of the row)
+            const int g0 = s8 >> 2, g1 = g0 + 1;
+            const float4 x0 = *reinterpret_cast<const float4*>(Xs + lo.rows[g0 & 7] + (g0 & ~7) * 4);
+            const float4 x1 = *reinterpret_cast<const float4*>(Xs + lo.rows[g1 & 7] + (g1 & ~7) * 4);
+            acc = MFMA_BF(pack8(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w),
+                          pack8(R[s8], R[s8 + 1], R[s8 + 2], R[s8 + 3], R[s8 + 4], R[s8 + 5], R[s8 + 6], R[s8 + 7]), acc);
+        }
+        return acc;
+    }
 #pragma unroll
     for (int s4 = 0; s4 < DP / 2; s4 += 4) {
         // granule index within the half = s4/4; its low 3 bits are swizzled (lane-constant table), the rest is an immediate
@@ -131,9 +155,29 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 }
 
 // acc[c] (dcol x lane-col) += Xs^T (rows = dcol, contraction over the 32 tile rows in krow order) . P (own registers)
-template <int DP>
+template <int DP, bool BF = false>
 __device__ __forceinline__ void mma_cols(f32x16 (&acc)[DP / 32], const float* __restrict__ Xs, const float (&P)[16],
                                          const LaneOff& lo, int d) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int c = 0; c < DP / 32; ++c) {
+            if (c * 32 < d) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {      // tile rows krow(r, half), r = 8s .. 8s+7: the same order in the P registers
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * s + j;
+                        x[j] = Xs[lo.cols[r & 3] + 8 * (r >> 2) * DP + c * 32];
+                    }
+                    acc[c] = MFMA_BF(pack8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]),
+                                     pack8(P[8 * s], P[8 * s + 1], P[8 * s + 2], P[8 * s + 3], P[8 * s + 4], P[8 * s + 5], P[8 * s + 6],
+                                           P[8 * s + 7]), acc[c]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < DP / 32; ++c) {
         if (c * 32 < d) {
@@ -166,7 +210,7 @@ __device__ __forceinline__ void store_cols(const f32x16 (&acc)[DP / 32], float* 
     } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int DP, bool DROP>
+template <int DP, bool DROP, bool BF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int TS = 32 * DP;                 // floats per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -211,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         const float* Vs = Ks + TS;
         const int j0 = t * 32;
 
-        const f32x16 S = mma_rows<DP>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
         float P[16];
         float mt = -INFINITY;
 #pragma unroll
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                 P[r] = bits >= thr ? P[r] * ik : 0.f;
             }
         }
-        mma_cols<DP>(O, Vs, P, lo, a.d);
+        mma_cols<DP, BF>(O, Vs, P, lo, a.d);
     }
     if (qvalid) {
         store_cols<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq + qi, col0, a.d, half, 1.0f / l);
@@ -283,7 +327,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
     }
 }
 
-template <int DP, bool DROP>
+template <int DP, bool DROP, bool BF>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -330,8 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         const float* Vs = Ks + TS;
         const int j0 = t * 32;
 
-        const f32x16 S = mma_rows<DP>(Ks, Qr, lo);
-        const f32x16 dP = mma_rows<DP>(Vs, Gr, lo);
+        const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
+        const f32x16 dP = mma_rows<DP, BF>(Vs, Gr, lo);
         float dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -346,12 +390,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
                 dS[r] = p * (dp - dl);
             }
         }
-        mma_cols<DP>(dQ, Ks, dS, lo, a.d);
+        mma_cols<DP, BF>(dQ, Ks, dS, lo, a.d);
     }
     if (qvalid) store_cols<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq + qi, col0, a.d, half, a.scale);
 }
 
-template <int DP, bool DROP>
+template <int DP, bool DROP, bool BF>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -402,8 +446,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         const int i0 = t * 32;
 
         // S[query][key] and dP[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
-        const f32x16 S = mma_rows<DP>(Qs, Kr, lo);
-        const f32x16 dP = mma_rows<DP>(Gs, Vr, lo);
+        const f32x16 S = mma_rows<DP, BF>(Qs, Kr, lo);
+        const f32x16 dP = mma_rows<DP, BF>(Gs, Vr, lo);
         float Pt[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -420,8 +464,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
                 dS[r] = p * (dP[r] * keep - dsv[u]);
             }
         }
-        mma_cols<DP>(dV, Gs, Pt, lo, a.d);
-        mma_cols<DP>(dK, Qs, dS, lo, a.d);
+        mma_cols<DP, BF>(dV, Gs, Pt, lo, a.d);
+        mma_cols<DP, BF>(dK, Qs, dS, lo, a.d);
     }
     if (kvalid) {
         store_cols<DP>(dV, a.dv, a.lddv, (int64_t)n * a.Tk + kj, col0, a.d, half, 1.0f);
@@ -471,19 +515,24 @@ static int check_common(const char* who, const AttnArgs& a) {
     return 0;
 }
 
-#define DISPATCH_DP_DROP(KERNEL, grid, block, lds_fn, s, a)                                                   \
+#define DISPATCH_DP_DROP_BF(KERNEL, BFV, grid, block, lds_fn, s, a)                                            \
     do {                                                                                                     \
         const bool drop_ = (a).p_drop > 0.f;                                                                 \
         if ((a).d <= 32) {                                                                                   \
-            if (drop_) hipLaunchKernelGGL((KERNEL<32, true>), grid, block, lds_fn(32), s, a);                \
-            else hipLaunchKernelGGL((KERNEL<32, false>), grid, block, lds_fn(32), s, a);                     \
+            if (drop_) hipLaunchKernelGGL((KERNEL<32, true, BFV>), grid, block, lds_fn(32), s, a);           \
+            else hipLaunchKernelGGL((KERNEL<32, false, BFV>), grid, block, lds_fn(32), s, a);                \
         } else if ((a).d <= 64) {                                                                            \
-            if (drop_) hipLaunchKernelGGL((KERNEL<64, true>), grid, block, lds_fn(64), s, a);                \
-            else hipLaunchKernelGGL((KERNEL<64, false>), grid, block, lds_fn(64), s, a);                     \
+            if (drop_) hipLaunchKernelGGL((KERNEL<64, true, BFV>), grid, block, lds_fn(64), s, a);           \
+            else hipLaunchKernelGGL((KERNEL<64, false, BFV>), grid, block, lds_fn(64), s, a);                \
         } else {                                                                                             \
-            if (drop_) hipLaunchKernelGGL((KERNEL<128, true>), grid, block, lds_fn(128), s, a);              \
-            else hipLaunchKernelGGL((KERNEL<128, false>), grid, block, lds_fn(128), s, a);                   \
+            if (drop_) hipLaunchKernelGGL((KERNEL<128, true, BFV>), grid, block, lds_fn(128), s, a);         \
+            else hipLaunchKernelGGL((KERNEL<128, false, BFV>), grid, block, lds_fn(128), s, a);              \
         }                                                                                                    \
+    } while (0)
+#define DISPATCH_DP_DROP(KERNEL, grid, block, lds_fn, s, a)                           \
+    do {                                                                              \
+        if ((a).bf16) DISPATCH_DP_DROP_BF(KERNEL, true, grid, block, lds_fn, s, a);   \
+        else DISPATCH_DP_DROP_BF(KERNEL, false, grid, block, lds_fn, s, a);           \
     } while (0)
 
 static int g_rows = 0;     // length of the streamed dimension (mask / lse rows staged whole in LDS); set before each dispatch
@@ -494,10 +543,11 @@ static size_t lds_bwd(int dp) { return (size_t)(4 * 32 * dp + 2 * ((g_rows + 31)
 
 using namespace ytvln;
 
-extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                  const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
-                                  int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
+static int attn_fwd_impl(int bf16, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                         const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                         int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
     AttnArgs a = {};
+    a.bf16 = bf16;
     a.q = q; a.k = k; a.v = v; a.mask = mask; a.out = ctx; a.lse_out = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
@@ -513,12 +563,26 @@ extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, i
     return 0;
 }
 
-extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                  const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
-                                  float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
-                                  int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
-                                  int64_t site, void* stream) {
+extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                                  int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
+    return attn_fwd_impl(0, q, ldq, k, ldk, v, ldv, mask, ctx, ldo, lse, N, heads, Tq, Tk, d, scale, p_drop, rng, site, stream);
+}
+
+extern "C" int ytvln_attn_fwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                   const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                                   int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(d % 8 == 0, "attn_fwd_bf16: head dim %d must be a multiple of 8", d);
+    return attn_fwd_impl(1, q, ldq, k, ldk, v, ldv, mask, ctx, ldo, lse, N, heads, Tq, Tk, d, scale, p_drop, rng, site, stream);
+}
+
+static int attn_bwd_impl(int bf16, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                         const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
+                         float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                         int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
+                         int64_t site, void* stream) {
     AttnArgs a = {};
+    a.bf16 = bf16;
     a.q = q; a.k = k; a.v = v; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta;
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
@@ -559,6 +623,25 @@ extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, i
     }
     YT_LAUNCH_CHECK("attn_bwd");
     return 0;
+}
+
+extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
+                                  float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                                  int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
+                                  int64_t site, void* stream) {
+    return attn_bwd_impl(0, q, ldq, k, ldk, v, ldv, mask, ctx, dctx, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, N, heads, Tq, Tk, d,
+                         scale, p_drop, rng, site, stream);
+}
+
+extern "C" int ytvln_attn_bwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                   const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
+                                   float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                                   int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
+                                   int64_t site, void* stream) {
+    YT_REQUIRE(d % 8 == 0, "attn_bwd_bf16: head dim %d must be a multiple of 8", d);
+    return attn_bwd_impl(1, q, ldq, k, ldk, v, ldv, mask, ctx, dctx, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, N, heads, Tq, Tk, d,
+                         scale, p_drop, rng, site, stream);
 }
 
 extern "C" int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,

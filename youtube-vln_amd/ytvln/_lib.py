@@ -31,6 +31,9 @@ SIGNATURES = {
     "ytvln_gather_rows_f32": [P, I64, P, I32, I32, P, P],
     "ytvln_randomize_tokens": [P, P, I64, I32, I64, P, P, P, I64, P, P, P],
     "ytvln_randomize_regions": [P, I64, P, P, I64, I32, I32, P, P, I64, P, P, P],
+    "ytvln_attn_fwd_bf16": [P, I64, P, I64, P, I64, P, P, I64, P, I32, I32, I32, I32, I32, F32, F32, P, I64, P],
+    "ytvln_attn_bwd_bf16": [P, I64, P, I64, P, I64, P, P, P, I64, P, P, P, I64, P, I64, P, I64, I32, I32, I32, I32, I32,
+                           F32, F32, P, I64, P],
     "ytvln_cast_bf16": [P, I64, I32, I32, I32, P, I64, P],
     "ytvln_gemm_bf16_nt": [P, I64, P, I64, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, P],
     "ytvln_ln_fwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],

@@ -669,7 +669,7 @@ def dropout(x: Tensor, p: float, training: bool, drop: Optional[DropoutState]) -
 # ------------------------------------------------------------------------------------------------------------------
 def _attn_fwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, N, heads, Tq, Tk, d, scale, p, rng, site):
     lse = torch.empty((N, heads, Tq), dtype=torch.float32, device=out.device)
-    call("ytvln_attn_fwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), out.shape[-1],
+    call("ytvln_attn_fwd_bf16" if (_MATMUL_PRECISION == "bf16" and d % 8 == 0) else "ytvln_attn_fwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), out.shape[-1],
          _ptr(lse), N, heads, Tq, Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
     return lse
 
@@ -677,7 +677,7 @@ def _attn_fwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, N, heads, 
 def _attn_bwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, dout, lse, dq, dq_off, lddq, dk, dk_off, lddk, dv, dv_off,
               lddv, N, heads, Tq, Tk, d, scale, p, rng, site):
     delta = torch.empty_like(lse)
-    call("ytvln_attn_bwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), _ptr(dout),
+    call("ytvln_attn_bwd_bf16" if (_MATMUL_PRECISION == "bf16" and d % 8 == 0) else "ytvln_attn_bwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), _ptr(dout),
          out.shape[-1], _ptr(lse), _ptr(delta), _ptr(dq, dq_off), lddq, _ptr(dk, dk_off), lddk, _ptr(dv, dv_off), lddv, N, heads, Tq,
          Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
 
