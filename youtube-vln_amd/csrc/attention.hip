@@ -226,6 +226,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int ntiles = (a.Tk + 31) >> 5;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
+    auto issue = [&](int t) {
+        float* st = smem + (t & 1) * 2 * TS;
+        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+    };
+    issue(0);                                   // first K/V tile travels while the Q fragment and the mask row are fetched
+
     float Qr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[(int64_t)n * a.Tk + j] : 0.f) : -INFINITY;
@@ -242,12 +249,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));      // score row id; element = (row id, key)
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
-    auto issue = [&](int t) {
-        float* st = smem + (t & 1) * 2 * TS;
-        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-    };
-    issue(0);
     for (int t = 0; t < ntiles; ++t) {
         TILE_WAIT_AND_SYNC();                      // tile t landed for everyone; everyone finished reading the other stage
         if (t + 1 < ntiles) issue(t + 1);
@@ -342,6 +343,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int ntiles = (a.Tk + 31) >> 5;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
+    auto issue = [&](int t) {
+        float* st = smem + (t & 1) * 2 * TS;
+        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
+    };
+    issue(0);                                   // first K/V tile travels while the register fragments are fetched
+
     float Qr[DP / 2], Gr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     load_rowfrag<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
@@ -361,12 +369,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const uint32_t dlo = (uint32_t)sidx;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
-    auto issue = [&](int t) {
-        float* st = smem + (t & 1) * 2 * TS;
-        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-    };
-    issue(0);
     for (int t = 0; t < ntiles; ++t) {
         TILE_WAIT_AND_SYNC();
         if (t + 1 < ntiles) issue(t + 1);
@@ -412,6 +414,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     const int col0 = h * a.d;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
+    auto issue = [&](int t) {
+        float* st = smem + (t & 1) * 2 * TS;
+        Tile<DP>::issue(st, a.q, a.ldq, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.dctx, a.ldo, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+    };
+    issue(0);                                   // first Q/dO tile travels while the register fragments and the lse/delta rows are fetched
+
     float Kr[DP / 2], Vr[DP / 2];
     load_rowfrag<DP>(Kr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
     load_rowfrag<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
@@ -432,12 +441,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     uint32_t thr = 0; float ik = 1.f;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
-    auto issue = [&](int t) {
-        float* st = smem + (t & 1) * 2 * TS;
-        Tile<DP>::issue(st, a.q, a.ldq, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.dctx, a.ldo, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
-    };
-    issue(0);
     for (int t = 0; t < nqt; ++t) {
         TILE_WAIT_AND_SYNC();
         if (t + 1 < nqt) issue(t + 1);
