@@ -293,10 +293,10 @@ struct DmaTile {
     static constexpr int NI = BMN * KB / 256 / NW;  // 1 KiB pieces per wave per k-tile (BMN*KB/256 pieces, NW waves)
     static constexpr int GR = KB / 4;               // 16-byte granules per row of a K-contiguous image (8 or 4)
     static constexpr int RP = 256 / KB;             // rows per 1 KiB piece of a K-contiguous image (8 or 16)
-    static_assert(NI >= 1 && (KB == 32 || KB == 16), "unsupported DMA tile");
+    static_assert(NI >= 1 && (KB == 64 || KB == 32 || KB == 16), "unsupported DMA tile");
     // XOR swizzle of a K-contiguous image: chosen so that the 16 rows of each ds_read_b128 lane group
     // ({0-3,12-15,20-27} / {4-11,16-19,28-31}) fall on 16 distinct 16-byte slots of the 256-byte bank row.
-    __device__ static __forceinline__ int swz(int m) { return KB == 32 ? ((m >> 1) & 7) : ((m >> 2) & 3); }
+    __device__ static __forceinline__ int swz(int m) { return KB == 64 ? (m & 15) : KB == 32 ? ((m >> 1) & 7) : ((m >> 2) & 3); }
     // per-lane source pointer of piece i for the tile starting at k0 (advanced by the caller)
     // MN: extent used for clamping rows (K-contiguous operand) / 16-byte column granules (M/N-contiguous operand);
     // kmax: last valid k row of an M/N-contiguous operand (rows past it are clamped: they meet zero padding of the other
@@ -557,6 +557,7 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
         if constexpr (BM == 128 && BN == 128) {
             if (cfg == 1) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
+            else if (cfg == 2 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
             else YT_DMA(8, 32, 2, 4);
         } else {
             YT_DMA(4, 32, 2, 2);
