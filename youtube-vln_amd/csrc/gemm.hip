@@ -555,7 +555,9 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
-        if constexpr (BM == 256 && BN == 128) {
+        if constexpr (BM == 256 && BN == 256) {
+            YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
+        } else if constexpr (BM == 256 && BN == 128) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x64, one workgroup per CU
         } else if constexpr (BM == 128 && BN == 128) {
             if (cfg == 1) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
@@ -712,11 +714,12 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
                            ldc, bias, M, N, g.splits, beta);
     } else {
         g.splits = 1;
-        // Outputs with at least ~2 full waves of 256x128 tiles (the 16128-row image-stream projections) take the larger tile: a
-        // quarter fewer operand bytes and a third fewer LDS fragment reads per MFMA, +2-4 % on those shapes (one workgroup per CU
-        // delivers the CU's rate, see plan_cost).  YTVLN_GEMM_BIG=0 switches it off.
-        static const int big = getenv("YTVLN_GEMM_BIG") ? atoi(getenv("YTVLN_GEMM_BIG")) : 1;
-        if (big && g.fast && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 128) >= 480) launch_tile<256, 128>(g, transA, transB, s);
+        // Outputs with about a full wave of 256x256 (else two of 256x128) tiles -- the 16128-row image-stream projections -- take the
+        // larger tile: half (a quarter) fewer operand bytes and fewer LDS fragment reads per MFMA; measured +5-8 % (+2-4 %) on those
+        // shapes over 128x128 (one workgroup per CU delivers the CU's rate, see plan_cost).  YTVLN_GEMM_BIG=0 / 1 restrict it.
+        static const int big = getenv("YTVLN_GEMM_BIG") ? atoi(getenv("YTVLN_GEMM_BIG")) : 2;
+        if (big == 2 && g.fast && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 256) >= 240) launch_tile<256, 256>(g, transA, transB, s);
+        else if (big && g.fast && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 128) >= 480) launch_tile<256, 128>(g, transA, transB, s);
         else if (plan.tile == 0) launch_tile<128, 128>(g, transA, transB, s);
         else if (plan.tile == 1) launch_tile<128, 64>(g, transA, transB, s);
         else launch_tile<64, 64>(g, transA, transB, s);
