@@ -718,8 +718,9 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         // larger tile: half (a quarter) fewer operand bytes and fewer LDS fragment reads per MFMA; measured +5-8 % (+2-4 %) on those
         // shapes over 128x128 (one workgroup per CU delivers the CU's rate, see plan_cost).  YTVLN_GEMM_BIG=0 / 1 restrict it.
         static const int big = getenv("YTVLN_GEMM_BIG") ? atoi(getenv("YTVLN_GEMM_BIG")) : 2;
-        if (big == 2 && g.fast && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 256) >= 240) launch_tile<256, 256>(g, transA, transB, s);
-        else if (big && g.fast && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 128) >= 480) launch_tile<256, 128>(g, transA, transB, s);
+        // (not for an M-contiguous A: its fragments are four ds_read_b32 each and the wide wave tiles lose, 121 -> 99 TFLOP/s on 30522x768x4480)
+        if (big == 2 && g.fast && !transA && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 256) >= 240) launch_tile<256, 256>(g, transA, transB, s);
+        else if (big && g.fast && !transA && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 128) >= 480) launch_tile<256, 128>(g, transA, transB, s);
         else if (plan.tile == 0) launch_tile<128, 128>(g, transA, transB, s);
         else if (plan.tile == 1) launch_tile<128, 64>(g, transA, transB, s);
         else launch_tile<64, 64>(g, transA, transB, s);
