@@ -480,30 +480,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //  * per block: a fixed cost (prologue DMA round trip + epilogue) plus k-tiles at the CU-exclusive rate of the tile shape
 //    (128x128 / 8 waves: 2.14 us per 32-deep k-tile; 128x64 and 64x64 / 4 waves: 1.14 and 0.55 us);
 //  * split-K (plain epilogues only, 128x128 tiles) adds the workspace round trip and the reduce launch.
-struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64
+struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
 
 static double plan_cost(int M, int N, int K, int tile, int sp) {
-    static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-    static const double tk[3] = {2.14, 1.14, 0.55}, tfix[3] = {5.0, 3.0, 3.0};
+    // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
+    static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
+    static const double tk[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
     const int splits = (int)cdiv(K, kchunk);
     const double blocks = (double)(cdiv(M, bm[tile]) * cdiv(N, bn[tile])) * splits;
     const double waves = ceil(blocks / 256.0);
     // the 4-wave tiles only reach their rate with 2-3 blocks co-resident on a CU (one block = one wave per SIMD)
-    const double need = tile == 0 ? 1.0 : tile == 1 ? 2.0 : 3.0, per_cu = std::max(1.0, blocks / 256.0);
+    const double need = tile == 1 ? 2.0 : tile == 2 ? 3.0 : 1.0, per_cu = std::max(1.0, blocks / 256.0);
     const double occ = per_cu < need ? need / per_cu : 1.0;
     double t = waves * (tfix[tile] + (double)(kchunk / BK) * tk[tile] * occ);
     if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / 3.0e6;     // us: launch + bytes at ~3 TB/s
     return t;
 }
 
-static Plan plan_gemm(int M, int N, int K, int epilogue) {
+// big_ok: the 256-row tiles are only used with a K-contiguous A on the LDS-DMA path (an M-contiguous A needs four ds_read_b32 per
+// fragment and loses with the wide wave tiles: 121 -> 99 TFLOP/s on 30522x768x4480).
+static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false) {
     Plan best = {0, 1};
     double best_t = 1e30;
     const int force_tile = getenv("YTVLN_GEMM_TILE") ? atoi(getenv("YTVLN_GEMM_TILE")) : -1;       // experiment knobs
     const int force_sp = getenv("YTVLN_GEMM_SPLITS") ? atoi(getenv("YTVLN_GEMM_SPLITS")) : -1;
-    for (int tile = 0; tile < 3; ++tile) {
+    static const int big = getenv("YTVLN_GEMM_BIG") ? atoi(getenv("YTVLN_GEMM_BIG")) : 2;          // 0: no 256-row tiles, 1: 256x128 only
+    for (int tile = 0; tile < 5; ++tile) {
         if (force_tile >= 0 && tile != force_tile) continue;
+        if (tile >= 3 && (!big_ok || big < tile - 2 || M < 256)) continue;
         const int smax = (tile == 0 && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
@@ -692,7 +697,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
     g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
              !getenv("YTVLN_GEMM_GENERIC");
-    Plan plan = plan_gemm(M, N, K, epilogue);
+    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && !transA);
     const int want = plan.splits;
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
@@ -714,13 +719,8 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
                            ldc, bias, M, N, g.splits, beta);
     } else {
         g.splits = 1;
-        // Outputs with about a full wave of 256x256 (else two of 256x128) tiles -- the 16128-row image-stream projections -- take the
-        // larger tile: half (a quarter) fewer operand bytes and fewer LDS fragment reads per MFMA; measured +5-8 % (+2-4 %) on those
-        // shapes over 128x128 (one workgroup per CU delivers the CU's rate, see plan_cost).  YTVLN_GEMM_BIG=0 / 1 restrict it.
-        static const int big = getenv("YTVLN_GEMM_BIG") ? atoi(getenv("YTVLN_GEMM_BIG")) : 2;
-        // (not for an M-contiguous A: its fragments are four ds_read_b32 each and the wide wave tiles lose, 121 -> 99 TFLOP/s on 30522x768x4480)
-        if (big == 2 && g.fast && !transA && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 256) >= 240) launch_tile<256, 256>(g, transA, transB, s);
-        else if (big && g.fast && !transA && plan.tile == 0 && cdiv(M, 256) * cdiv(N, 128) >= 480) launch_tile<256, 128>(g, transA, transB, s);
+        if (plan.tile == 4) launch_tile<256, 256>(g, transA, transB, s);
+        else if (plan.tile == 3) launch_tile<256, 128>(g, transA, transB, s);
         else if (plan.tile == 0) launch_tile<128, 128>(g, transA, transB, s);
         else if (plan.tile == 1) launch_tile<128, 64>(g, transA, transB, s);
         else launch_tile<64, 64>(g, transA, transB, s);
