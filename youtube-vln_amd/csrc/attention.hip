@@ -538,9 +538,9 @@ static int check_common(const char* who, const AttnArgs& a) {
         else DISPATCH_DP_DROP_BF(KERNEL, false, grid, block, lds_fn, s, a);           \
     } while (0)
 
-static int g_rows = 0;     // length of the streamed dimension (mask / lse rows staged whole in LDS); set before each dispatch
-static size_t lds_fwd(int dp) { return (size_t)(4 * 32 * dp + ((g_rows + 31) / 32) * 32) * sizeof(float); }
-static size_t lds_bwd(int dp) { return (size_t)(4 * 32 * dp + 2 * ((g_rows + 31) / 32) * 32) * sizeof(float); }
+// dynamic LDS: the two-stage tile ring + the streamed dimension's mask row (forward / dQ) or lse and delta rows (dK/dV), staged whole
+struct LdsFwd { int rows; size_t operator()(int dp) const { return (size_t)(4 * 32 * dp + ((rows + 31) / 32) * 32) * sizeof(float); } };
+struct LdsBwd { int rows; size_t operator()(int dp) const { return (size_t)(4 * 32 * dp + 2 * ((rows + 31) / 32) * 32) * sizeof(float); } };
 
 }  // namespace ytvln
 
@@ -560,7 +560,7 @@ static int attn_fwd_impl(int bf16, const float* q, int64_t ldq, const float* k, 
     dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
     hipStream_t s = as_stream(stream);
     YT_REQUIRE(Tk <= 8192 && Tq <= 8192, "attn_fwd: sequence too long for the LDS-resident mask row");
-    g_rows = Tk;
+    const LdsFwd lds_fwd{Tk};
     DISPATCH_DP_DROP(attn_fwd_kernel, grid, block, lds_fwd, s, a);
     YT_LAUNCH_CHECK("attn_fwd");
     return 0;
@@ -615,13 +615,13 @@ static int attn_bwd_impl(int bf16, const float* q, int64_t ldq, const float* k, 
     {
         const int nw = pick_waves(Tq);
         dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
-        g_rows = Tk;
+        const LdsFwd lds_fwd{Tk};
         DISPATCH_DP_DROP(attn_bwd_dq_kernel, grid, block, lds_fwd, s, a);
     }
     {
         const int nw = pick_waves(Tk);
         dim3 grid((unsigned)cdiv(Tk, 32 * nw), heads, N), block(64 * nw);
-        g_rows = Tq;
+        const LdsBwd lds_bwd{Tq};
         DISPATCH_DP_DROP(attn_bwd_dkv_kernel, grid, block, lds_bwd, s, a);
     }
     YT_LAUNCH_CHECK("attn_bwd");
