@@ -174,6 +174,27 @@ int ytvln_attn_bwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk
                         int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
                         int64_t site, void* stream);
 
+/* Both directions of BertBiAttention (vilbert.py:552-618) in ONE launch per kernel: text queries over region keys/values and region
+ * queries over text keys/values are independent problems of complementary shape (T x R and R x T); one grid holds the workgroups of
+ * both, so the slots one direction's last partial round would leave idle are filled by the other.  Each problem is described like the
+ * arguments of ytvln_attn_fwd_f32 / ytvln_attn_bwd_f32 (forward reads q,k,v,mask and writes ctx,lse; backward reads
+ * q,k,v,mask,ctx_in,dctx,lse_in and writes delta,dq,dk,dv); N, heads, d, scale, rng and the operand precision are shared.  Falls back to
+ * two ordinary launches when the two problems need different workgroup shapes. */
+typedef struct ytvln_attn_problem {
+    const float *q, *k, *v, *mask;
+    const float *ctx_in, *dctx, *lse_in;
+    float *ctx, *lse, *delta, *dq, *dk, *dv;
+    int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int32_t Tq, Tk;
+    float p_drop;
+    int32_t reserved;
+    int64_t site;
+} ytvln_attn_problem;
+int ytvln_attn_fwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
+                        const int64_t* rng, int bf16, void* stream);
+int ytvln_attn_bwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
+                        const int64_t* rng, int bf16, void* stream);
+
 /* probs[n,h,i,j] = exp(q_i.k_j*scale + mask - lse): the attention_probs tensor the reference returns when
  * output_all_attention_masks=True (vilbert.py:300, 311).  Diagnostic path, not on the training step. */
 int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,

@@ -38,3 +38,36 @@ for name, h, d, Tq, Tk in cases:
     if not fwd_only:
         line += f" | bwd {res[1][0]*1000:7.1f} us {res[1][1]:6.1f} TF/s"
     print(line + " (algorithmic flops 4*N*h*Tq*Tk*d fwd, 14*... bwd)", flush=True)
+
+# both BertBiAttention directions in ONE launch per kernel (ytvln_attn_fwd_pair / ytvln_attn_bwd_pair), as CoAttentionFn runs them
+if not only or only.startswith("co"):
+    h, d, T, R = 8, 128, 80, 288
+    Hb = h * d
+    q1, kv1 = torch.randn(N * R, Hb, device=dev), torch.randn(N * R, 2 * Hb, device=dev)
+    q2, kv2 = torch.randn(N * T, Hb, device=dev), torch.randn(N * T, 2 * Hb, device=dev)
+    m1, m2 = torch.zeros(N, R, device=dev), torch.zeros(N, T, device=dev)
+    for t in (q1, kv1, q2, kv2):
+        t.requires_grad_(True)
+    st2 = ops.DropoutState(dev)
+
+    def pair_fwd():
+        return ops.CoAttentionFn.apply(q1, kv1, q2, kv2, m1, m2, N, R, T, h, p, p, st2.tensor if p > 0 else None, 5, 6)
+    c1, c2, _, _ = pair_fwd()
+    g1, g2 = torch.randn_like(c1), torch.randn_like(c2)
+
+    def pair_fb():
+        a, b, _, _ = pair_fwd()
+        torch.autograd.backward([a, b], [g1, g2])
+    res = []
+    for f in (pair_fwd,) if fwd_only else (pair_fwd, pair_fb):
+        for _ in range(3): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 10 * 1000)
+    fl = 2 * 4.0 * N * h * T * R * d
+    line = f"co pair   fwd {res[0]:7.1f} us {fl / res[0] / 1e6:6.1f} TF/s"
+    if not fwd_only:
+        line += f" | fwd+bwd {res[1]:7.1f} us (bwd {res[1] - res[0]:7.1f} us {3.5 * fl / (res[1] - res[0]) / 1e6:6.1f} TF/s)"
+    print(line + "   <- both directions, one launch per kernel", flush=True)

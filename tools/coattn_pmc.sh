@@ -12,6 +12,8 @@ f = glob.glob("/tmp/copmc/*counter_collection.csv")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     if "attn_fwd" in r["Kernel_Name"]:
+        if "pair" in r["Kernel_Name"]:
+            acc["pair_launch"][r["Counter_Name"]].append(float(r["Counter_Value"])); continue
         acc[r["Grid_Size"] if "Grid_Size" in r else "all"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for grid, d in acc.items():

@@ -211,7 +211,7 @@ __device__ __forceinline__ void store_cols(const f32x16 (&acc)[DP / 32], float* 
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int DP, bool DROP, bool BF>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP;                 // floats per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage0: K V][stage1: K V][mask row, -inf past Tk]
@@ -219,8 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int n = blockIdx.z, h = blockIdx.y;
-    const int qi = (blockIdx.x * nw + wave) * 32 + l31;
+    const int qi = (bx * nw + wave) * 32 + l31;
     const bool qvalid = qi < a.Tq;
     const int col0 = h * a.d;
     const int ntiles = (a.Tk + 31) >> 5;
@@ -329,15 +328,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 template <int DP, bool DROP, bool BF>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Mrow = smem + 4 * TS;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int n = blockIdx.z, h = blockIdx.y;
-    const int qi = (blockIdx.x * nw + wave) * 32 + l31;
+    const int qi = (bx * nw + wave) * 32 + l31;
     const bool qvalid = qi < a.Tq;
     const int col0 = h * a.d;
     const int ntiles = (a.Tk + 31) >> 5;
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 template <int DP, bool DROP, bool BF>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage0: Q dO][stage1: Q dO][lse row, +inf past Tq][delta row]
@@ -408,8 +406,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int n = blockIdx.z, h = blockIdx.y;
-    const int kj = (blockIdx.x * nw + wave) * 32 + l31;    // this lane's key
+    const int kj = (bx * nw + wave) * 32 + l31;    // this lane's key
     const bool kvalid = kj < a.Tk;
     const int col0 = h * a.d;
     const LaneOff lo = make_lane_off<DP>(l31, half);
@@ -496,6 +493,30 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict
     }
 }
 
+// ---- kernel entry points: one problem per launch (3-D grid), or the two directions of BertBiAttention in ONE launch (1-D grid:
+// the first nb0 workgroups belong to direction 0).  The pair launch lets the hardware dispatcher fill the slots that one
+// direction's last partial round would leave idle with the other direction's workgroups.
+struct AttnPair { AttnArgs p[2]; int nb0, gx0, gx1; };
+
+#define YT_ATTN_KERNELS(NAME, BODY, LB)                                                                                  \
+    template <int DP, bool DROP, bool BF>                                                                                \
+    __global__ LB void NAME##_kernel(const AttnArgs a) { BODY<DP, DROP, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z); }    \
+    template <int DP, bool DROP, bool BF>                                                                                \
+    __global__ LB void NAME##_pair_kernel(const AttnPair b) {                                                            \
+        int bid = blockIdx.x;                                                                                            \
+        if (bid < b.nb0) {                                                                                               \
+            BODY<DP, DROP, BF>(b.p[0], bid % b.gx0, (bid / b.gx0) % b.p[0].heads, bid / (b.gx0 * b.p[0].heads));         \
+        } else {                                                                                                         \
+            bid -= b.nb0;                                                                                                \
+            BODY<DP, DROP, BF>(b.p[1], bid % b.gx1, (bid / b.gx1) % b.p[1].heads, bid / (b.gx1 * b.p[1].heads));         \
+        }                                                                                                                \
+    }
+YT_ATTN_KERNELS(attn_fwd, attn_fwd_body, __launch_bounds__(256, 2))
+YT_ATTN_KERNELS(attn_bwd_dq, attn_bwd_dq_body, __launch_bounds__(256, 2))
+YT_ATTN_KERNELS(attn_bwd_dkv, attn_bwd_dkv_body, __launch_bounds__(256))
+#undef YT_ATTN_KERNELS
+
+
 static int pick_waves(int T) {
     // waves per workgroup (32 rows each): least padding first, then the most waves (they share the staged tiles)
     int best = 1, best_pad = 1 << 30;
@@ -545,6 +566,25 @@ struct LdsBwd { int rows; size_t operator()(int dp) const { return (size_t)(4 * 
 }  // namespace ytvln
 
 using namespace ytvln;
+
+static void launch_delta(const float* ctx, const float* dctx, int64_t ldo, float* delta, int N, int heads, int Tq, int d, hipStream_t s) {
+    const int64_t total = (int64_t)N * Tq * heads;
+    {
+        const int d4 = d / 4;
+        const int lg = d4 <= 1 ? 1 : d4 <= 2 ? 2 : d4 <= 4 ? 4 : d4 <= 8 ? 8 : d4 <= 16 ? 16 : 32;
+        const dim3 dgrid((unsigned)std::min<int64_t>(cdiv(total * lg, 256), 8192));
+#define YT_DELTA(L) hipLaunchKernelGGL(attn_delta_kernel<L>, dgrid, dim3(256), 0, s, ctx, dctx, ldo, delta, N, heads, Tq, d)
+        switch (lg) {
+            case 1: YT_DELTA(1); break;
+            case 2: YT_DELTA(2); break;
+            case 4: YT_DELTA(4); break;
+            case 8: YT_DELTA(8); break;
+            case 16: YT_DELTA(16); break;
+            default: YT_DELTA(32); break;
+        }
+#undef YT_DELTA
+    }
+}
 
 static int attn_fwd_impl(int bf16, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                          const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
@@ -597,21 +637,7 @@ static int attn_bwd_impl(int bf16, const float* q, int64_t ldq, const float* k, 
     YT_REQUIRE((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0, "attn_bwd: misaligned pointer");
     hipStream_t s = as_stream(stream);
     const int64_t total = (int64_t)N * Tq * heads;
-    {
-        const int d4 = d / 4;
-        const int lg = d4 <= 1 ? 1 : d4 <= 2 ? 2 : d4 <= 4 ? 4 : d4 <= 8 ? 8 : d4 <= 16 ? 16 : 32;
-        const dim3 dgrid((unsigned)std::min<int64_t>(cdiv(total * lg, 256), 8192));
-#define YT_DELTA(L) hipLaunchKernelGGL(attn_delta_kernel<L>, dgrid, dim3(256), 0, s, ctx, dctx, ldo, delta, N, heads, Tq, d)
-        switch (lg) {
-            case 1: YT_DELTA(1); break;
-            case 2: YT_DELTA(2); break;
-            case 4: YT_DELTA(4); break;
-            case 8: YT_DELTA(8); break;
-            case 16: YT_DELTA(16); break;
-            default: YT_DELTA(32); break;
-        }
-#undef YT_DELTA
-    }
+    launch_delta(ctx, dctx, ldo, delta, N, heads, Tq, d, s);
     {
         const int nw = pick_waves(Tq);
         dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
@@ -645,6 +671,117 @@ extern "C" int ytvln_attn_bwd_bf16(const float* q, int64_t ldq, const float* k, 
     YT_REQUIRE(d % 8 == 0, "attn_bwd_bf16: head dim %d must be a multiple of 8", d);
     return attn_bwd_impl(1, q, ldq, k, ldk, v, ldv, mask, ctx, dctx, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, N, heads, Tq, Tk, d,
                          scale, p_drop, rng, site, stream);
+}
+
+// ---- both directions of BertBiAttention in one launch -----------------------------------------------------------------------
+static void fill_args(AttnArgs& a, const ytvln_attn_problem& pr, int N, int heads, int d, float scale, const int64_t* rng, int bf16) {
+    a = AttnArgs{};
+    a.q = pr.q; a.k = pr.k; a.v = pr.v; a.mask = pr.mask;
+    a.ctx = pr.ctx_in; a.dctx = pr.dctx; a.lse = pr.lse_in; a.delta = pr.delta;
+    a.out = pr.ctx; a.lse_out = pr.lse; a.dq = pr.dq; a.dk = pr.dk; a.dv = pr.dv;
+    a.ldq = pr.ldq; a.ldk = pr.ldk; a.ldv = pr.ldv; a.ldo = pr.ldo; a.lddq = pr.lddq; a.lddk = pr.lddk; a.lddv = pr.lddv;
+    a.N = N; a.heads = heads; a.Tq = pr.Tq; a.Tk = pr.Tk; a.d = d; a.scale = scale; a.p_drop = pr.p_drop; a.rng = rng; a.site = pr.site;
+    a.bf16 = bf16;
+}
+
+#define DISPATCH_PAIR_BF(KERNEL, BFV, drop_, grid, block, lds, s, b)                                           \
+    do {                                                                                                     \
+        if ((b).p[0].d <= 32) {                                                                              \
+            if (drop_) hipLaunchKernelGGL((KERNEL<32, true, BFV>), grid, block, lds(32), s, b);              \
+            else hipLaunchKernelGGL((KERNEL<32, false, BFV>), grid, block, lds(32), s, b);                   \
+        } else if ((b).p[0].d <= 64) {                                                                       \
+            if (drop_) hipLaunchKernelGGL((KERNEL<64, true, BFV>), grid, block, lds(64), s, b);              \
+            else hipLaunchKernelGGL((KERNEL<64, false, BFV>), grid, block, lds(64), s, b);                   \
+        } else {                                                                                             \
+            if (drop_) hipLaunchKernelGGL((KERNEL<128, true, BFV>), grid, block, lds(128), s, b);            \
+            else hipLaunchKernelGGL((KERNEL<128, false, BFV>), grid, block, lds(128), s, b);                 \
+        }                                                                                                    \
+    } while (0)
+#define DISPATCH_PAIR(KERNEL, drop_, grid, block, lds, s, b)                              \
+    do {                                                                                  \
+        if ((b).p[0].bf16) DISPATCH_PAIR_BF(KERNEL, true, drop_, grid, block, lds, s, b); \
+        else DISPATCH_PAIR_BF(KERNEL, false, drop_, grid, block, lds, s, b);              \
+    } while (0)
+
+extern "C" int ytvln_attn_fwd_pair(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,
+                                   const int64_t* rng, int bf16, void* stream) {
+    YT_REQUIRE(pa && pb, "attn_fwd_pair: null problem");
+    const int nwa = pick_waves(pa->Tq), nwb = pick_waves(pb->Tq);
+    const bool dropa = pa->p_drop > 0.f, dropb = pb->p_drop > 0.f;
+    if (nwa != nwb || (bf16 && d % 8 != 0)) {       // different workgroup shapes: two ordinary launches
+        const ytvln_attn_problem* ps[2] = {pa, pb};
+        for (const ytvln_attn_problem* p : ps)
+            if (int rc = attn_fwd_impl(bf16 && d % 8 == 0, p->q, p->ldq, p->k, p->ldk, p->v, p->ldv, p->mask, p->ctx, p->ldo, p->lse, N, heads,
+                                       p->Tq, p->Tk, d, scale, p->p_drop, rng, p->site, stream))
+                return rc;
+        return 0;
+    }
+    AttnPair b;
+    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf16);
+    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf16);
+    for (int i = 0; i < 2; ++i) {
+        if (int rc = check_common("attn_fwd_pair", b.p[i])) return rc;
+        YT_REQUIRE(b.p[i].out && b.p[i].lse_out && ((uintptr_t)b.p[i].out & 15) == 0, "attn_fwd_pair: ctx/lse null or misaligned");
+        YT_REQUIRE(b.p[i].Tk <= 8192 && b.p[i].Tq <= 8192, "attn_fwd_pair: sequence too long for the LDS-resident mask row");
+    }
+    b.gx0 = (int)cdiv(pa->Tq, 32 * nwa); b.gx1 = (int)cdiv(pb->Tq, 32 * nwa);
+    b.nb0 = b.gx0 * heads * N;
+    const int64_t total = (int64_t)b.nb0 + (int64_t)b.gx1 * heads * N;
+    YT_REQUIRE(total < (1ll << 31), "attn_fwd_pair: grid too large");
+    const LdsFwd lds{std::max(pa->Tk, pb->Tk)};
+    hipStream_t s = as_stream(stream);
+    DISPATCH_PAIR(attn_fwd_pair_kernel, (dropa || dropb), dim3((unsigned)total), dim3(64 * nwa), lds, s, b);
+    YT_LAUNCH_CHECK("attn_fwd_pair");
+    return 0;
+}
+
+extern "C" int ytvln_attn_bwd_pair(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,
+                                   const int64_t* rng, int bf16, void* stream) {
+    YT_REQUIRE(pa && pb, "attn_bwd_pair: null problem");
+    const bool same = pick_waves(pa->Tq) == pick_waves(pb->Tq) && pick_waves(pa->Tk) == pick_waves(pb->Tk) && !(bf16 && d % 8 != 0);
+    if (!same) {
+        const ytvln_attn_problem* ps[2] = {pa, pb};
+        for (const ytvln_attn_problem* p : ps)
+            if (int rc = attn_bwd_impl(bf16 && d % 8 == 0, p->q, p->ldq, p->k, p->ldk, p->v, p->ldv, p->mask, p->ctx_in, p->dctx, p->ldo, p->lse_in,
+                                       p->delta, p->dq, p->lddq, p->dk, p->lddk, p->dv, p->lddv, N, heads, p->Tq, p->Tk, d, scale, p->p_drop,
+                                       rng, p->site, stream))
+                return rc;
+        return 0;
+    }
+    AttnPair b;
+    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf16);
+    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf16);
+    hipStream_t s = as_stream(stream);
+    for (int i = 0; i < 2; ++i) {
+        const AttnArgs& a = b.p[i];
+        if (int rc = check_common("attn_bwd_pair", a)) return rc;
+        YT_REQUIRE(a.ctx && a.dctx && a.lse && a.delta && a.dq && a.dk && a.dv, "attn_bwd_pair: null pointer");
+        YT_REQUIRE(a.Tk <= 8192 && a.Tq <= 8192, "attn_bwd_pair: sequence too long for the LDS-resident mask / lse rows");
+        YT_REQUIRE(a.lddq % 4 == 0 && a.lddk % 4 == 0 && a.lddv % 4 == 0, "attn_bwd_pair: gradient leading dimensions must be multiples of 4");
+        YT_REQUIRE((((uintptr_t)a.ctx | (uintptr_t)a.dctx | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) & 15) == 0, "attn_bwd_pair: misaligned pointer");
+        launch_delta(a.ctx, a.dctx, a.ldo, (i == 0 ? pa : pb)->delta, N, heads, a.Tq, d, s);
+    }
+    const bool drop = pa->p_drop > 0.f || pb->p_drop > 0.f;
+    {
+        const int nw = pick_waves(pa->Tq);
+        b.gx0 = (int)cdiv(pa->Tq, 32 * nw); b.gx1 = (int)cdiv(pb->Tq, 32 * nw);
+        b.nb0 = b.gx0 * heads * N;
+        const int64_t total = (int64_t)b.nb0 + (int64_t)b.gx1 * heads * N;
+        YT_REQUIRE(total < (1ll << 31), "attn_bwd_pair: grid too large");
+        const LdsFwd lds{std::max(pa->Tk, pb->Tk)};
+        DISPATCH_PAIR(attn_bwd_dq_pair_kernel, drop, dim3((unsigned)total), dim3(64 * nw), lds, s, b);
+    }
+    {
+        const int nw = pick_waves(pa->Tk);
+        b.gx0 = (int)cdiv(pa->Tk, 32 * nw); b.gx1 = (int)cdiv(pb->Tk, 32 * nw);
+        b.nb0 = b.gx0 * heads * N;
+        const int64_t total = (int64_t)b.nb0 + (int64_t)b.gx1 * heads * N;
+        YT_REQUIRE(total < (1ll << 31), "attn_bwd_pair: grid too large");
+        const LdsBwd lds{std::max(pa->Tq, pb->Tq)};
+        DISPATCH_PAIR(attn_bwd_dkv_pair_kernel, drop, dim3((unsigned)total), dim3(64 * nw), lds, s, b);
+    }
+    YT_LAUNCH_CHECK("attn_bwd_pair");
+    return 0;
 }
 
 extern "C" int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,

@@ -22,6 +22,13 @@ class YtvlnLibraryError(RuntimeError):
 P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
 # name -> argtypes, exactly mirroring include/ytvln.h (tests/test_abi.py checks header <-> table <-> exported symbols)
+class AttnProblem(C.Structure):
+    """`ytvln_attn_problem` of include/ytvln.h."""
+    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "mask", "ctx_in", "dctx", "lse_in", "ctx", "lse", "delta", "dq", "dk", "dv")] + \
+               [(n, C.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddq", "lddk", "lddv")] + \
+               [("Tq", C.c_int32), ("Tk", C.c_int32), ("p_drop", C.c_float), ("reserved", C.c_int32), ("site", C.c_int64)]
+
+
 SIGNATURES = {
     "ytvln_gemm_workspace_elems": [I32, I32, I32, I32],
     "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P],
@@ -34,6 +41,8 @@ SIGNATURES = {
     "ytvln_attn_fwd_bf16": [P, I64, P, I64, P, I64, P, P, I64, P, I32, I32, I32, I32, I32, F32, F32, P, I64, P],
     "ytvln_attn_bwd_bf16": [P, I64, P, I64, P, I64, P, P, P, I64, P, P, P, I64, P, I64, P, I64, I32, I32, I32, I32, I32,
                            F32, F32, P, I64, P],
+    "ytvln_attn_fwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
+    "ytvln_attn_bwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
     "ytvln_cast_bf16": [P, I64, I32, I32, I32, P, I64, P],
     "ytvln_gemm_bf16_nt": [P, I64, P, I64, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, P],
     "ytvln_ln_fwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],

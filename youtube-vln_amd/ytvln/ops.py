@@ -682,6 +682,25 @@ def _attn_bwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, dout, lse,
          Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
 
 
+def _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=None, lse=None, ctx_in=None, dctx=None,
+                  lse_in=None, delta=None, dq=None, dq_off=0, lddq=0, dk=None, dk_off=0, lddk=0, dv=None, dv_off=0, lddv=0):
+    pr = _lib.AttnProblem()
+    pr.q, pr.k, pr.v, pr.mask = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), _ptr(mask)
+    pr.ctx, pr.lse = _ptr(ctx), _ptr(lse)
+    pr.ctx_in, pr.dctx, pr.lse_in, pr.delta = _ptr(ctx_in), _ptr(dctx), _ptr(lse_in), _ptr(delta)
+    pr.dq, pr.dk, pr.dv = _ptr(dq, dq_off), _ptr(dk, dk_off), _ptr(dv, dv_off)
+    o = ctx if ctx is not None else ctx_in
+    pr.ldq, pr.ldk, pr.ldv, pr.ldo, pr.lddq, pr.lddk, pr.lddv = ldq, ldk, ldv, o.shape[-1], lddq, lddk, lddv
+    pr.Tq, pr.Tk, pr.p_drop, pr.site = Tq, Tk, float(p), int(site)
+    return pr
+
+
+def _attn_pair(name, pa, pb, N, heads, d, scale, rng):
+    import ctypes
+    call(name, ctypes.addressof(pa), ctypes.addressof(pb), N, heads, d, float(scale), _ptr(rng) if rng is not None else None,
+         int(_MATMUL_PRECISION == "bf16" and d % 8 == 0), _stream())
+
+
 def attn_probs(q, q_off, ldq, k, k_off, ldk, mask, lse, N, heads, Tq, Tk, d, scale) -> Tensor:
     probs = torch.empty((N, heads, Tq, Tk), dtype=torch.float32, device=lse.device)
     call("ytvln_attn_probs_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(mask), _ptr(lse), _ptr(probs), N, heads, Tq, Tk, d,
@@ -738,8 +757,13 @@ class CoAttentionFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(d)
         ctx1 = torch.empty((N * T, Hb), dtype=torch.float32, device=q1.device)
         ctx2 = torch.empty((N * R, Hb), dtype=torch.float32, device=q1.device)
-        lse1 = _attn_fwd(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, ctx1, N, heads, T, R, d, scale, p1, rng, site1)
-        lse2 = _attn_fwd(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, ctx2, N, heads, R, T, d, scale, p2, rng, site2)
+        lse1 = torch.empty((N, heads, T), dtype=torch.float32, device=q1.device)
+        lse2 = torch.empty((N, heads, R), dtype=torch.float32, device=q1.device)
+        # both directions in one launch (text queries over regions | region queries over text)
+        _attn_pair("ytvln_attn_fwd_pair",
+                   _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx=ctx1, lse=lse1),
+                   _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx=ctx2, lse=lse2),
+                   N, heads, d, scale, rng)
         ctx.meta = (N, R, T, heads, Hb, d, scale, p1, p2, site1, site2)
         ctx.save_for_backward(q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng)
         ctx.mark_non_differentiable(lse1, lse2)
@@ -751,6 +775,18 @@ class CoAttentionFn(torch.autograd.Function):
         q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng = ctx.saved_tensors
         N, R, T, heads, Hb, d, scale, p1, p2, site1, site2 = ctx.meta
         gq1 = gkv1 = gq2 = gkv2 = None
+        if d1 is not None and d2 is not None:       # the usual case: both directions in one launch per kernel
+            d1 = d1 if d1.is_contiguous() else d1.contiguous()
+            d2 = d2 if d2.is_contiguous() else d2.contiguous()
+            gq2, gkv1, gq1, gkv2 = torch.empty_like(q2), torch.empty_like(kv1), torch.empty_like(q1), torch.empty_like(kv2)
+            delta1, delta2 = torch.empty_like(lse1), torch.empty_like(lse2)
+            _attn_pair("ytvln_attn_bwd_pair",
+                       _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx_in=ctx1, dctx=d1, lse_in=lse1,
+                                     delta=delta1, dq=gq2, lddq=Hb, dk=gkv1, lddk=2 * Hb, dv=gkv1, dv_off=Hb, lddv=2 * Hb),
+                       _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx_in=ctx2, dctx=d2, lse_in=lse2,
+                                     delta=delta2, dq=gq1, lddq=Hb, dk=gkv2, lddk=2 * Hb, dv=gkv2, dv_off=Hb, lddv=2 * Hb),
+                       N, heads, d, scale, rng)
+            return (gq1, gkv1, gq2, gkv2) + (None,) * 11
         if d1 is not None:      # text queries over image keys/values -> dq2, dk1|dv1
             d1 = d1 if d1.is_contiguous() else d1.contiguous()
             gq2, gkv1 = torch.empty_like(q2), torch.empty_like(kv1)
