@@ -165,3 +165,28 @@ def test_head_row_selection_is_static_and_ordered():
     flag = torch.tensor([0, 1, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
     assert ops.select_rows(flag, 4).tolist() == [1, 3, 4, 7]
     assert ops.select_rows(flag, 6).tolist()[:4] == [1, 3, 4, 7]          # the tail holds un-flagged rows (ignored targets)
+
+
+def test_feature_store_readers_match_reference_golden():
+    """ytvln.features (on-disk region-feature format, both field conventions, two key schemes, several stores) against the outputs of the
+    reference's BnBFeaturesReader / YTbFeaturesReader on the same records (tests/golden/g8_features.npz, oracle/gen_golden_features.py)."""
+    import pickle
+    import numpy as np
+    from helpers import gold
+    from ytvln import features as F
+    g = gold("g8_features.npz")
+    stores = {k[len("store_"):]: pickle.loads(g[k].tobytes()) for k in g.files if k.startswith("store_")}
+    r = F.BnBFeaturesReader([stores["bnb_old"], stores["bnb_new"]])
+    assert len(r) == 3
+    f, l, p = r[("12-7", "98-3", "12-1")]
+    for got, ref in ((f, g["bnb_f"]), (l, g["bnb_l"]), (p, g["bnb_p"])):
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    f, l, p = F.YTbFeaturesReader(stores["ytb_new"])[("vidB/000031", "vidA/000010")]
+    for got, ref in ((f, g["ytb_f"]), (l, g["ytb_l"]), (p, g["ytb_p"])):
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    assert np.allclose(f[0], f[1:].mean(0)) and list(l[0]) == [0, 0, 1, 1, 1, 0, 1, 0, 1, 0, 1] and np.allclose(p[0], 1 / 1601)
+    import pytest
+    with pytest.raises(TypeError):
+        r[("no-such-key",)]
+    with pytest.raises(RuntimeError, match="preload keys"):
+        F.FeaturesReader({b"12-1": b""})
