@@ -77,6 +77,22 @@ r = FR.BnBFeaturesReader(["bnb_old", "bnb_new"])
 out["bnb_f"], out["bnb_l"], out["bnb_p"] = r[("12-7", "98-3", "12-1")]
 r = FR.YTbFeaturesReader("ytb_new")
 out["ytb_f"], out["ytb_l"], out["ytb_p"] = r[("vidB/000031", "vidA/000010")]
+
+
+def pano_record(nb):
+    r = record(nb, False)
+    r["vfov"] = 60
+    for k, n in (("viewHeading", 36), ("viewElevation", 36), ("featureHeading", nb), ("featureElevation", nb), ("featureViewIndex", nb)):
+        r[k] = base64.b64encode(rs.uniform(-3.1, 3.1, n).astype(np.float32).tobytes())
+    return r
+
+
+pano_keys = ["scanA-vp1", "scanA-vp2", "scanB-vp9"]
+STORES["pano"] = {k.encode(): pickle.dumps(pano_record(int(rs.randint(3, 9)))) for k in pano_keys}
+STORES["pano"][b"keys"] = pickle.dumps([k.encode() for k in pano_keys])
+r = FR.PanoFeaturesReader("pano")
+out["pano_f"], out["pano_l"], out["pano_p"] = r[("scanA-vp2", 0.7, -1.9)]
+out["pano_viewpoints"] = np.array(sorted(f"{s}:{v}" for s, vs in r.viewpoints.items() for v in vs))
 blob = {name: np.frombuffer(pickle.dumps(d), dtype=np.uint8) for name, d in STORES.items()}
 np.savez_compressed(os.path.join(os.path.dirname(HERE), "tests", "golden", "g8_features.npz"), **out, **{"store_" + k: v for k, v in blob.items()})
 print("wrote g8_features.npz", {k: v.shape for k, v in out.items()})

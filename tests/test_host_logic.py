@@ -185,6 +185,11 @@ def test_feature_store_readers_match_reference_golden():
     for got, ref in ((f, g["ytb_f"]), (l, g["ytb_l"]), (p, g["ytb_p"])):
         assert got.dtype == ref.dtype and np.array_equal(got, ref)
     assert np.allclose(f[0], f[1:].mean(0)) and list(l[0]) == [0, 0, 1, 1, 1, 0, 1, 0, 1, 0, 1] and np.allclose(p[0], 1 / 1601)
+    pr = F.PanoFeaturesReader(stores["pano"])
+    f, l, p = pr[("scanA-vp2", 0.7, -1.9)]
+    for got, ref in ((f, g["pano_f"]), (l, g["pano_l"]), (p, g["pano_p"])):
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    assert sorted(f"{s}:{v}" for s, vs in pr.viewpoints.items() for v in vs) == g["pano_viewpoints"].tolist()
     import pytest
     with pytest.raises(TypeError):
         r[("no-such-key",)]

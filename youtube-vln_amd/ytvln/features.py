@@ -177,3 +177,62 @@ class BnBFeaturesReader(BaseFeaturesReader):
 class YTbFeaturesReader(BaseFeaturesReader):
     def _split_key(self, key: str):
         return key.split("/")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Room-to-Room panoramas (features_reader.py:193-341): one record per viewpoint, keys "scan-viewpoint"; every region also carries a
+# heading / elevation, and the location vector encodes them relative to the agent's current and next heading.
+# ------------------------------------------------------------------------------------------------------------------
+_PANO_ARRAYS = (("features", (-1, FEATURE_DIM)), ("boxes", (-1, 4)), ("cls_prob", (-1, NUM_CLASSES)), ("viewHeading", None),
+                ("viewElevation", None), ("featureHeading", None), ("featureElevation", None), ("featureViewIndex", None))
+
+
+def decode_pano_record(item: Dict) -> Dict:
+    """features_reader.py:193-236 (`_convert_item`): base64 fields -> fp32 arrays, sizes -> ints."""
+    out = dict(item)
+    for k in ("image_w", "image_h", "vfov"):
+        out[k] = int(item[k])
+    for k, shape in _PANO_ARRAYS:
+        a = np.frombuffer(base64.b64decode(item[k]), dtype=np.float32)
+        out[k] = a.reshape(shape) if shape else a
+    return out
+
+
+def pano_locations(boxes5: np.ndarray, feat_headings: np.ndarray, feat_elevations: np.ndarray, heading: float, next_heading: float) -> np.ndarray:
+    """features_reader.py:258-282 (`_get_locations`)."""
+    loc = np.ones((len(boxes5), 11), dtype=np.float32)
+    loc[:, :5] = boxes5[:, :5]
+    loc[:, 5] = np.sin(feat_headings - heading)
+    loc[:, 6] = np.cos(feat_headings - heading)
+    loc[:, 7] = np.sin(feat_elevations)
+    loc[:, 8] = np.cos(feat_elevations)
+    loc[:, 9] = np.sin(feat_headings - next_heading)
+    loc[:, 10] = np.cos(feat_headings - next_heading)
+    return loc
+
+
+class PanoFeaturesReader(FeaturesReader):
+    """features_reader.py:285-341: `reader[(key, heading, next_heading)]` -> (features, locations, probs) with the global region first."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.viewpoints: Dict[str, set] = {}
+        for key in self.keys:
+            scan_id, viewpoint_id = key.split("-")
+            self.viewpoints.setdefault(scan_id, set()).add(viewpoint_id)
+
+    def __getitem__(self, query: Tuple):
+        key, heading, next_heading = query
+        if key not in self.keys:
+            raise TypeError(f"invalid key: {key}")
+        with self.envs[self.keys[key]].begin(write=False) as txn:
+            item = decode_pano_record(pickle.loads(bytes(txn.get(key.encode()))))
+        rec = Record(None, None, len(item["boxes"]), item["image_w"], item["image_h"], item["cls_prob"], item["features"], item["boxes"])
+        features, probs = item["features"], item["cls_prob"]
+        locations = pano_locations(normalise_boxes(rec), item["featureHeading"], item["featureElevation"], heading, next_heading)
+        g_feature = features.mean(axis=0, keepdims=True)
+        g_location = np.array([[0, 0, 1, 1, 1, np.sin(0 - heading), np.cos(0 - heading), np.sin(0), np.cos(0),
+                                np.sin(0 - next_heading), np.cos(0 - next_heading)]])
+        g_prob = np.ones(shape=(1, NUM_CLASSES)) / NUM_CLASSES
+        return (np.concatenate([g_feature, features], axis=0), np.concatenate([g_location, locations], axis=0),
+                np.concatenate([g_prob, probs], axis=0))
