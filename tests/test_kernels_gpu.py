@@ -1,5 +1,6 @@
 """Parity of every C-ABI kernel with a plain fp64/fp32 torch restatement of the same op (GPU box only)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -718,3 +719,34 @@ def test_attention_bf16_operands(dev, lib, N, heads, d, Tq, Tk):
     assert rel_l2(dk.reshape(N, Tk, H), kd.grad) < 2e-2, rel_l2(dk.reshape(N, Tk, H), kd.grad)
     assert rel_l2(dv.reshape(N, Tk, H), vd.grad) < 2e-2, rel_l2(dv.reshape(N, Tk, H), vd.grad)
     assert rel_l2(o, outs["fp32"][0]) > 1e-5, "bf16 attention reproduced the fp32 kernel: the bf16 path did not run"
+
+
+def test_gemm_streamk_opt_in(dev, lib):
+    """The opt-in stream-K schedule (YTVLN_GEMM_STREAMK=2; the planner is read once per process, hence the subprocess): equal work per
+    resident workgroup, partial tiles exchanged through write-through stores and relaxed flags, owner applies the epilogue.  Checks
+    value parity with fp64, bit-reproducibility between two launches, and that ragged M / N and fused epilogues work."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from ytvln import ops
+dev = torch.device("cuda", 0)
+for (M, N, K, ta, tb, epi) in [(4480, 768, 3072, 0, 1, 0), (4480, 768, 1536, 0, 0, 0), (2600, 1000, 1024, 0, 1, 1), (768, 3072, 4480, 1, 0, 0)]:
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = torch.empty(M, N, device=dev); aux = torch.empty(M, N, device=dev)
+    run = lambda: ops._gemm(A, A.stride(0), ta, B, B.stride(0), tb, C, N, M, N, K, bias=bias, aux=aux, ldaux=N, epi=epi)
+    run(); first = C.clone(); run()
+    assert torch.equal(first, C), "stream-K must be deterministic"
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()
+    if epi: ref = torch.nn.functional.gelu(ref)
+    err = float((C.double() - ref).abs().max())
+    assert err < 2e-4 * (K ** 0.5) / 30, (M, N, K, err)
+print("STREAMK_OK")
+""" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd")
+    env = dict(os.environ, YTVLN_GEMM_STREAMK="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "STREAMK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

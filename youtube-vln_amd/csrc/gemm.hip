@@ -31,6 +31,7 @@ struct GemmArgs {
     int Kloop;            // contraction length the fast kernel iterates over (K rounded up to 32 when A's K tail is zero-padded)
     int mnA, mnB;         // clamp extents of the operands in their M / N dimension (rounded up to 4 inside padding)
     int ktail;            // 1: the last k-tile reaches past K -> M/N-contiguous operands clamp their k rows to K-1
+    int* sk_flags;        // stream-K: one arrival flag per workgroup (zeroed before the launch); partials live in ws
 };
 
 constexpr int BK = 32;
@@ -42,11 +43,10 @@ constexpr int BK = 32;
 //    column-by-column ("grouped" order), so the ~64 tiles resident on an XCD form an 8 x 8 patch that shares 8 A panels and
 //    8 B panels instead of 2-3 rows x 24 columns.
 struct TileCoord { int m, n, split; };
-__device__ __forceinline__ TileCoord decode_tile(int bid, int tiles_m, int tiles_n, int splits) {
+// linear tile index (already XCD-local) -> tile row / column in "grouped" order
+__device__ __forceinline__ TileCoord tile_coord(int t, int tiles_m, int tiles_n) {
     TileCoord c;
-    int t;
-    if (splits > 1) { c.split = bid % splits; t = bid / splits; }
-    else { c.split = 0; t = xcd_remap(bid, tiles_m * tiles_n); }
+    c.split = 0;
     constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * tiles_n;
     const int g = t / per_group, first_m = g * GROUP_M;
@@ -54,6 +54,14 @@ __device__ __forceinline__ TileCoord decode_tile(int bid, int tiles_m, int tiles
     const int r = t - g * per_group;
     c.m = first_m + r % rows;
     c.n = r / rows;
+    return c;
+}
+__device__ __forceinline__ TileCoord decode_tile(int bid, int tiles_m, int tiles_n, int splits) {
+    int t, split;
+    if (splits > 1) { split = bid % splits; t = bid / splits; }
+    else { split = 0; t = xcd_remap(bid, tiles_m * tiles_n); }
+    TileCoord c = tile_coord(t, tiles_m, tiles_n);
+    c.split = split;
     return c;
 }
 
@@ -442,6 +450,152 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
 }
 
+// Cross-XCD exchange of stream-K partial tiles without cache-wide fences (guide, section 5.7): write-through (sc1) 16-byte stores,
+// vmcnt drain, workgroup barrier, ONE relaxed agent-scope flag store; the owner polls the flag relaxed (an acquire poll would invalidate
+// its L1 on every iteration) and reads the slab with sc1 loads.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1(float* p, v4f v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ v4f load_sc1(const float* p) {      // the caller waits (s_waitcnt vmcnt(0)) before using the value
+    v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// ---- stream-K ---------------------------------------------------------------------------------------------------------------------
+// For outputs whose 128x128 tile count does not fill whole waves of the 256 CUs (the 4480-row text-stream projections: 35 x 6 = 210
+// tiles = 82 % of one wave, 35 x 24 = 840 = 82 % of four).  The (tile, k-tile) iteration space, tile-major, is cut into gridDim equal
+// contiguous ranges, one per resident workgroup (gridDim <= 512, so all of them run concurrently).  A range may start or end inside
+// a tile:
+//   * a segment that does not start at k = 0 is a CONTRIBUTION: its accumulators go to ws[position] (fragment order) and the
+//     workgroup raises its flag (release, agent scope);
+//   * the workgroup whose segment starts at k = 0 OWNS the tile: if the segment stops short of K it waits for the flags of the
+//     following positions until the tile is covered, adds their partials in position order (deterministic) and runs the ordinary
+//     epilogue -- bias, GELU, ... work unchanged, unlike split-K.
+// A range visits the end of tile A first and the beginning of tile B last, so contributions are produced early and consumed late:
+// owners practically never spin.  Positions are XCD-remapped workgroup ids: neighbours in the iteration space share an L2.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 4) void gemm_streamk_kernel(const GemmArgs g) {
+    constexpr int BM = 128, BN = 128, NW = 8, KB = 32, NS = 2;
+    using TA = DmaTile<BM, A_KC, NW, KB>;
+    using TB = DmaTile<BN, B_KC, NW, KB>;
+    constexpr int TM = 1, TN = 2;
+    constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
+    constexpr int NG = KB / 8;
+    __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    const int nkt = g.Kloop / KB;                                   // k-tiles per output tile
+    const int64_t total = (int64_t)g.ntiles * nkt;
+    const int G = gridDim.x;
+    const int pos = xcd_remap(blockIdx.x, G);
+    int64_t it = total * pos / G;
+    const int64_t it_end = total * (pos + 1) / G;
+    const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
+    float* myws = g.ws + (int64_t)pos * (BM * BN);
+
+    while (it < it_end) {
+        const int tile = (int)(it / nkt), k0 = (int)(it - (int64_t)tile * nkt);
+        const int k1 = (int)min((int64_t)nkt, it_end - (int64_t)tile * nkt);      // this segment: k-tiles [k0, k1) of `tile`
+        const TileCoord tc = tile_coord(tile, g.tiles_m, g.tiles_n);
+        const int m0 = tc.m * BM, n0 = tc.n * BN;
+        const float* pa[TA::NI];
+        const float* pb[TB::NI];
+#pragma unroll
+        for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, k0 * KB, wave, lane, i, 0x7fffffff);
+#pragma unroll
+        for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, k0 * KB, wave, lane, i, 0x7fffffff);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+        const int nk = k1 - k0;
+        auto issue = [&](int kt) {
+            float* As = smem + (kt & 1) * STAGE;
+            float* Bs = As + SA;
+#pragma unroll
+            for (int i = 0; i < TA::NI; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
+                pa[i] += sa;
+            }
+#pragma unroll
+            for (int i = 0; i < TB::NI; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
+                pb[i] += sb;
+            }
+        };
+        __builtin_amdgcn_s_barrier();                 // the previous segment's last stage is no longer being read
+        issue(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) issue(kt + 1);
+            const float* As = smem + (kt & 1) * STAGE;
+            const float* Bs = As + SA;
+#pragma unroll
+            for (int sg = 0; sg < NG; ++sg) {
+                float4 a[TM], b[TN];
+                a[0] = TA::frag(As, wm0, 0, l31, half, sg);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[j].x, acc[0][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[j].y, acc[0][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[j].z, acc[0][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[j].w, acc[0][j], 0, 0, 0);
+                }
+            }
+        }
+        if (k0 != 0) {
+            // contribution: fragment-order dump (lane-contiguous 16-byte write-through stores), then publish
+            float* dst = myws + (int64_t)tid * 32;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f v = {acc[0][j][4 * q], acc[0][j][4 * q + 1], acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]};
+                    store_sc1(dst + (j * 4 + q) * 4, v);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(g.sk_flags + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (k1 < nkt) {
+                // owner of a tile that other positions finish: gather their partials in position order
+                int covered = k1, p = pos + 1;
+                while (covered < nkt) {
+                    if (tid == 0)
+                        while (__hip_atomic_load(g.sk_flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+                    __syncthreads();
+                    const float* src = g.ws + (int64_t)p * (BM * BN) + (int64_t)tid * 32;
+                    v4f part[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) part[u] = load_sc1(src + u * 4);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v4f v = part[j * 4 + q];
+                            acc[0][j][4 * q] += v[0]; acc[0][j][4 * q + 1] += v[1]; acc[0][j][4 * q + 2] += v[2]; acc[0][j][4 * q + 3] += v[3];
+                        }
+                    // position p covers from its start to min(tile end, its own end)
+                    const int64_t pend = total * (p + 1) / G;
+                    covered = (int)min((int64_t)nkt, pend - (int64_t)tile * nkt);
+                    ++p;
+                }
+            }
+            gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, 0);
+        }
+        it = (int64_t)tile * nkt + k1;
+    }
+}
+
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
                                                             const float* __restrict__ bias, int M, int N, int splits, float beta) {
@@ -480,7 +634,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //  * per block: a fixed cost (prologue DMA round trip + epilogue) plus k-tiles at the CU-exclusive rate of the tile shape
 //    (128x128 / 8 waves: 2.14 us per 32-deep k-tile; 128x64 and 64x64 / 4 waves: 1.14 and 0.55 us);
 //  * split-K (plain epilogues only, 128x128 tiles) adds the workspace round trip and the reduce launch.
-struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
+struct Plan { int tile; int splits; int streamk; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
+constexpr int SK_GRID = 512;                 // stream-K workgroups: two per CU, all resident
 
 static double plan_cost(int M, int N, int K, int tile, int sp) {
     // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
@@ -500,8 +655,8 @@ static double plan_cost(int M, int N, int K, int tile, int sp) {
 
 // big_ok: the 256-row tiles are only used with a K-contiguous A on the LDS-DMA path (an M-contiguous A needs four ds_read_b32 per
 // fragment and loses with the wide wave tiles: 121 -> 99 TFLOP/s on 30522x768x4480).
-static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false) {
-    Plan best = {0, 1};
+static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool sk_ok = false) {
+    Plan best = {0, 1, 0};
     double best_t = 1e30;
     const int force_tile = getenv("YTVLN_GEMM_TILE") ? atoi(getenv("YTVLN_GEMM_TILE")) : -1;       // experiment knobs
     const int force_sp = getenv("YTVLN_GEMM_SPLITS") ? atoi(getenv("YTVLN_GEMM_SPLITS")) : -1;
@@ -513,13 +668,26 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false) {
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
             const double t = plan_cost(M, N, K, tile, sp);
-            if (t < best_t * 0.98) { best_t = t; best = {tile, sp}; }       // fewer splits / larger tiles win near-ties
+            if (t < best_t * 0.98) { best_t = t; best = {tile, sp, 0}; }       // fewer splits / larger tiles win near-ties
+        }
+    }
+    // stream-K over 128x128 tiles (gemm_streamk_kernel): every one of the 512 resident workgroups gets the same number of k-tiles, any
+    // epilogue.  Measured on the 4480- and 7680-row text shapes it fills the idle CUs (+22 %) but pays ~30-35 us per workgroup for the
+    // partial-tile round trip and the second pipeline fill, all workgroups in lock-step: 0.97x / 0.95x of the best ordinary plan.
+    // Kept as an opt-in (YTVLN_GEMM_STREAMK=1: when the model predicts a win, =2: whenever legal); off by default.
+    static const int sk_on = getenv("YTVLN_GEMM_STREAMK") ? atoi(getenv("YTVLN_GEMM_STREAMK")) : 0;
+    if (sk_ok && sk_on && force_tile < 0 && force_sp < 0 && K % BK == 0) {
+        const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), nkt = K / BK;
+        if (tiles >= 96 && tiles * nkt >= 4 * SK_GRID) {
+            const double t = 35.0 + (double)cdiv(tiles * nkt, SK_GRID) * 4.28;
+            if (t < best_t * 0.95 || sk_on == 2) best = {0, 1, 1};
         }
     }
     return best;
 }
 
 static int plan_splits(int M, int N, int K, int epilogue) { return plan_gemm(M, N, K, epilogue).splits; }
+static int64_t streamk_ws_elems() { return (int64_t)SK_GRID * 128 * 128 + SK_GRID; }     // partial tiles + flags
 
 // bf16 launches (K counted in 4-byte words): matrix time is 8x shorter, so the legacy occupancy rule (fill whole rounds of the 512
 // resident workgroups, at least 8 k-tiles per split) is kept for them.
@@ -665,7 +833,9 @@ using namespace ytvln;
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
     const int splits = std::max(plan_splits(M, N, K, epilogue), plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points
-    return splits > 1 ? (int64_t)splits * M * N : 0;
+    int64_t need = splits > 1 ? (int64_t)splits * M * N : 0;
+    if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
+    return need;
 }
 
 extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
@@ -684,7 +854,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     hipStream_t s = as_stream(stream);
-    g.splits = 1; g.kchunk = K; g.ws = nullptr;
+    g.splits = 1; g.kchunk = K; g.ws = nullptr; g.sk_flags = nullptr;
     // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
     // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
     // B's k rows are clamped -- B must be [K,N]), and an M-contiguous A may have M % 4 != 0.
@@ -697,7 +867,20 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
     g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
              !getenv("YTVLN_GEMM_GENERIC");
-    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && !transA);
+    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && !transA, g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems());
+    if (plan.streamk) {
+        g.tiles_m = (int)cdiv(M, 128); g.tiles_n = (int)cdiv(N, 128); g.ntiles = g.tiles_m * g.tiles_n;
+        g.splits = 1; g.kchunk = g.Kloop; g.ws = workspace;
+        g.sk_flags = reinterpret_cast<int*>(workspace + (int64_t)SK_GRID * 128 * 128);
+        hipMemsetAsync(g.sk_flags, 0, SK_GRID * sizeof(int), s);
+        const dim3 grid(SK_GRID), blk(512);
+        if (!transA && transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, blk, 0, s, g);
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, blk, 0, s, g);
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<false, false>), grid, blk, 0, s, g);
+        else hipLaunchKernelGGL((gemm_streamk_kernel<false, true>), grid, blk, 0, s, g);
+        YT_LAUNCH_CHECK("gemm_f32 (stream-K)");
+        return 0;
+    }
     const int want = plan.splits;
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
@@ -762,7 +945,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias = bias; g.aux = aux;
     g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
-    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N;
+    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
     const int want = plan_splits_bf16(M, N, K / 2, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
