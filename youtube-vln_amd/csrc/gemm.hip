@@ -679,7 +679,7 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
     if (sk_ok && sk_on && force_tile < 0 && force_sp < 0 && K % BK == 0) {
         const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), nkt = K / BK;
         if (tiles >= 96 && tiles * nkt >= 4 * SK_GRID) {
-            const double t = 35.0 + (double)cdiv(tiles * nkt, SK_GRID) * 4.28;
+            const double t = 35.0 + (double)cdiv(tiles * nkt, 256) * 2.3;
             if (t < best_t * 0.95 || sk_on == 2) best = {0, 1, 1};
         }
     }
@@ -873,7 +873,8 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         g.splits = 1; g.kchunk = g.Kloop; g.ws = workspace;
         g.sk_flags = reinterpret_cast<int*>(workspace + (int64_t)SK_GRID * 128 * 128);
         hipMemsetAsync(g.sk_flags, 0, SK_GRID * sizeof(int), s);
-        const dim3 grid(SK_GRID), blk(512);
+        static const int skg = getenv("YTVLN_GEMM_SKGRID") ? std::min(SK_GRID, std::max(8, atoi(getenv("YTVLN_GEMM_SKGRID")) / 8 * 8)) : SK_GRID;
+        const dim3 grid(skg), blk(512);
         if (!transA && transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, blk, 0, s, g);
         else if (!transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, blk, 0, s, g);
         else if (transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<false, false>), grid, blk, 0, s, g);
