@@ -743,8 +743,8 @@ for (M, N, K, ta, tb, epi) in [(4480, 768, 3072, 0, 1, 0), (4480, 768, 1536, 0, 
     assert torch.equal(first, C), "stream-K must be deterministic"
     ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double()
     if epi: ref = torch.nn.functional.gelu(ref)
-    err = float((C.double() - ref).abs().max())
-    assert err < 2e-4 * (K ** 0.5) / 30, (M, N, K, err)
+    err = float((C.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-5, (M, N, K, err)
 print("STREAMK_OK")
 """ % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd")
     env = dict(os.environ, YTVLN_GEMM_STREAMK="2")
