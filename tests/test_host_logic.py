@@ -195,3 +195,23 @@ def test_feature_store_readers_match_reference_golden():
         r[("no-such-key",)]
     with pytest.raises(RuntimeError, match="preload keys"):
         F.FeaturesReader({b"12-1": b""})
+
+
+def test_dropin_aliases_resolve_reference_import_lines():
+    """ytvln.dropin.install(): the reference's own import statements (pretrain.py:16-17, vilbert_init.py) land on the MI355X modules.
+    Run in a subprocess so the aliases do not leak into the other tests (the oracle tests import the real reference elsewhere)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from ytvln import dropin; dropin.install()\n"
+        "from vilbert.vilbert import BertConfig, BertModel, BertPreTrainingHeads, BertForMultiModalPreTraining\n"
+        "from vilbert.optimization import AdamW, WarmupLinearSchedule\n"
+        "from vilbert.vilbert_init import get_optimization\n"
+        "from lily import Lily, BERT_CONFIG_FACTORY\n"
+        "import ytvln.vilbert, ytvln.lily\n"
+        "assert BertModel is ytvln.vilbert.BertModel and Lily is ytvln.lily.Lily and BERT_CONFIG_FACTORY['vilbert'] is BertConfig\n"
+        "print('DROPIN_OK')\n") % __import__("os").path.join(ROOT, "youtube-vln_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "DROPIN_OK" in r.stdout, r.stdout + r.stderr
