@@ -55,6 +55,9 @@ enum {
  *   logit gradients (vilbert.py:906, 968 backward) use the LDS-DMA main loop although 30522 % 32 != 0. */
 #define YTVLN_GEMM_A_ZERO_PADDED 1
 int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
+/* Introspection (host only, no GPU work): the tile shape and split count the launch planner picks for an aligned problem of this size
+ * (transA = 1: M-contiguous A, which excludes the 256-row tiles).  Used by tests and by tools/ to explain a measurement. */
+int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits);
 int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                    float beta, float* workspace, int64_t workspace_elems, int flags, void* stream);

@@ -94,3 +94,25 @@ def test_product_never_imports_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert "vilbert_ref" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_gemm_launch_planner_host_logic():
+    """ytvln_gemm_plan is pure host code: the cost model's choices for the BASELINE config-2 / config-4 shapes."""
+    import ctypes
+    from ytvln import _lib
+    lib = _lib.load()
+
+    def plan(M, N, K, transA=0, epi=0):
+        tm, tn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.ytvln_gemm_plan(M, N, K, transA, epi, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp)) == 0
+        return tm.value, tn.value, sp.value
+
+    assert plan(16128, 1024, 1024) == (256, 256, 1)            # image-stream projection: one wave of 252 big tiles
+    assert plan(24192, 1024, 1024)[:2] != (256, 256)           # config 4: 95 x 4 = 380 tiles of 256x256 would leave half a wave idle
+    assert plan(4480, 768, 3072) == (128, 128, 1)              # 210 tiles: one wave, no split-K round trip
+    assert plan(4480, 1024, 768)[:2] == (64, 64)               # 280 128x128 tiles = 55 % of two waves -> small tiles
+    tm, tn, sp = plan(1024, 1024, 16128, transA=1)             # weight gradient: few tiles, long contraction -> deterministic split-K
+    assert (tm, tn) == (128, 128) and sp >= 4
+    assert plan(1024, 1024, 16128, transA=1, epi=1)[2] == 1    # fused activations never split
+    assert plan(30522, 768, 4480, transA=1)[0] == 128          # an M-contiguous A never takes the 256-row tiles
+    assert lib.ytvln_gemm_plan(0, 8, 8, 0, 0, None, None, None) != 0

@@ -831,6 +831,14 @@ static void launch_bf16(GemmArgs& g, hipStream_t s) {
 
 using namespace ytvln;
 
+extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
+    YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan: bad argument");
+    static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
+    const Plan p = plan_gemm(M, N, K, epilogue, !transA, false);
+    *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
+    return 0;
+}
+
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
     const int splits = std::max(plan_splits(M, N, K, epilogue), plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points
     int64_t need = splits > 1 ? (int64_t)splits * M * N : 0;
