@@ -545,3 +545,34 @@ def test_cfg2_full_size_parity_and_properties(dev, lib):
     for k in per:
         if not k.startswith("correct_"):
             assert abs(float(mper[k]) - float(per[k])) < 2e-5, (k, float(mper[k]), float(per[k]))
+
+
+def test_cfg5_long_trajectory_shapes(dev, lib):
+    """BASELINE configs[4] shapes (16 frames x 36 regions = 576 regions per pair, T = 80, all four losses) on the tiny configuration so the
+    CPU oracle finishes in seconds: fp32 path within 1e-4 of the oracle's losses, bf16 MFMA mode within 2e-2 relative of them."""
+    import vilbert_ref as O
+    from ytvln import ops, synth
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    model, W = build_lily(dev, "tiny_2_2_1.json", args, seed=61)
+    model.train()
+    nb = synth.make_batch(bs=2, K=7, T=80, frames=16, boxes=36, seed=71, ignore_rank_frac=0.0)
+    batch = synth.to_torch(nb, dev)
+    S = {k: torch.from_numpy(v).clone() for k, v in W.items()}
+    flags = O.TaskFlags(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    cb = synth.to_torch(nb)
+    with torch.no_grad():
+        oout = O.lily_forward(S, O.RefConfig(**cfg_dict("tiny_2_2_1.json", **ZERO_DROP)), flags, *O.model_input(cb))
+        ototal, oper = O.total_loss(cb, oout, flags)
+    with torch.no_grad():
+        _, total, per = losses_of(model, batch, args)
+    for k, v in oper.items():
+        assert abs(float(per[k]) - float(v)) <= LOSS_TOL, (k, float(per[k]), float(v))
+    ops.set_matmul_precision("bf16")
+    try:
+        with torch.no_grad():
+            _, btotal, bper = losses_of(model, batch, args)
+    finally:
+        ops.set_matmul_precision("fp32")
+    for k, v in oper.items():
+        assert abs(float(bper[k]) - float(v)) <= 2e-2 * max(abs(float(v)), 1e-3), (k, float(bper[k]), float(v))
+    assert abs(float(btotal) - float(total)) > 0.0
