@@ -576,3 +576,38 @@ def test_cfg5_long_trajectory_shapes(dev, lib):
     for k, v in oper.items():
         assert abs(float(bper[k]) - float(v)) <= 2e-2 * max(abs(float(v)), 1e-3), (k, float(bper[k]), float(v))
     assert abs(float(btotal) - float(total)) > 0.0
+
+
+def test_gradient_accumulation_matches_big_batch_of_micro_steps(dev, lib):
+    """--gradient_accumulation_steps 2 (utils/utils_init.py:226-239): two micro-steps on two batches, each loss / 2, one optimizer step
+    == one step on the summed-and-halved gradients computed by hand.  Exercises the fall-back of the direct-to-arena gradient writes
+    (the second micro-step must ADD to the first one's gradients) and the DataParallel-free zero_grad path."""
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True, gradient_accumulation_steps=2)
+    args.learning_rate = 1e-3
+    b0 = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=81, ignore_rank_frac=0.0), dev)
+    b1 = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=82, ignore_rank_frac=0.0), dev)
+    model, _ = build_lily(dev, "micro.json", args, seed=9)
+    model.train()
+    opt, sched, _, _ = get_optimization(args, model, 10, None)
+    for rep in range(2):                                  # two optimizer steps = four micro-steps (arena exists from the second on)
+        U.train_step(model, opt, sched, b0, args, 2 * rep, all_options=True)
+        U.train_step(model, opt, sched, b1, args, 2 * rep + 1, all_options=True)
+    got = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+    ref_args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    ref_args.learning_rate = 1e-3
+    ref, _ = build_lily(dev, "micro.json", ref_args, seed=9)
+    ref.train()
+    ropt, rsched, _, _ = get_optimization(args, ref, 10, None)
+    for rep in range(2):
+        total = None
+        for b in (b0, b1):
+            _, l, _ = losses_of(ref, b, ref_args)
+            total = 0.5 * l if total is None else total + 0.5 * l
+        total.backward()
+        ropt.step(); rsched.step(); ropt.zero_grad()
+    want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).cpu()
+    assert float((got - want).abs().max()) < 3e-6, float((got - want).abs().max())
