@@ -55,7 +55,12 @@ def _worker(rank, world, port, q, mode="eager"):
     opt, sched, _, _ = get_optimization(args, model, 10, None)
     dp.attach(opt)
     batch = _batch(rank, dev)
-    if mode == "eager":
+    if mode == "accum":      # 2 micro-steps per optimizer step: the exchange happens once, on the accumulated gradients
+        args.gradient_accumulation_steps = 2
+        batch2 = _batch(rank + 2, dev)
+        for step in range(6):
+            U.train_step(dp, opt, sched, batch if step % 2 == 0 else batch2, args, step, all_options=True)
+    elif mode == "eager":
         for step in range(3):
             U.train_step(dp, opt, sched, batch, args, step, all_options=True)
     else:       # one eager step, then two replays of the two-graph step with the exchange between the graphs
@@ -78,7 +83,7 @@ def _worker(rank, world, port, q, mode="eager"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["eager", "graphed"])
+@pytest.mark.parametrize("mode", ["eager", "graphed", "accum"])
 def test_two_ranks_match_single_process_average(dev, lib, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -97,13 +102,15 @@ def test_two_ranks_match_single_process_average(dev, lib, mode):
     args.learning_rate = 1e-3
     opt, sched, _, _ = get_optimization(args, model, 10, None)
     batches = [_batch(r, dev) for r in range(2)]
+    if mode == "accum":       # per optimizer step every rank sees (batch_r, batch_{r+2}), each micro-loss / 2, ranks averaged
+        batches = [_batch(r, dev) for r in range(4)]
     for step in range(3):
         total = None
         for b in batches:
             outputs = model(*U.get_model_input(b, all_options=True))
             for task, flag in U.TASKS:
                 _, _, l, _ = U.get_loss_correct(b, outputs, task, args, None, True, all_options=True)
-                l = 0.5 * (args.traj_loss_scale * l if task == "traj" else l)
+                l = (1.0 / len(batches)) * (args.traj_loss_scale * l if task == "traj" else l)
                 total = l if total is None else total + l
         total.backward()
         opt.step(); sched.step(); opt.zero_grad()

@@ -190,6 +190,10 @@ def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=N
     accum = getattr(args, "gradient_accumulation_steps", 1)
     if accum > 1:
         loss = loss / accum
+        if hasattr(model, "require_backward_grad_sync"):
+            # data parallel: exchange the ACCUMULATED gradients once, during the last micro-step's backward (a bucket reduced after
+            # the first micro-step would be summed over ranks and then have un-reduced local gradients added to it)
+            model.require_backward_grad_sync = (step + 1) % accum == 0
     loss.backward()
     if not optimizer_step:          # forward/backward only (ytvln.distributed.GraphedTrainStep captures the update separately)
         return loss.detach(), reduced_metrics
