@@ -611,3 +611,54 @@ def test_gradient_accumulation_matches_big_batch_of_micro_steps(dev, lib):
         ropt.step(); rsched.step(); ropt.zero_grad()
     want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).cpu()
     assert float((got - want).abs().max()) < 3e-6, float((got - want).abs().max())
+
+
+def test_train_epoch_loop_and_nonstrict_checkpoint(dev, lib, tmp_path):
+    """train_epoch (utils/utils_init.py:192-268) over a host-side loader with a ragged opt_mask, logging through a writer object; then
+    `from_pretrained` on a checkpoint that LACKS the task heads / orientation embeddings (like the public Conceptual-Captions
+    pretrained_model.bin, vilbert.py:1161-1172): missing tensors keep their fresh initialisation, the rest is loaded."""
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.lily import Lily
+    from ytvln.vilbert import BertConfig
+    from ytvln.vilbert_init import get_optimization
+    # (no trajectory-judgement head here: with a ragged opt_mask pad_packed fills the missing options with -inf and the reference's own
+    #  BCE-with-logits turns that into NaN -- golden g0 records exactly that NaN, and test_g0 checks we reproduce it)
+    args = args_ns(ranking=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    model, W = build_lily(dev, "micro.json", args, seed=17)
+    opt, sched, _, _ = get_optimization(args, model, 10, None)
+    loader = [synth.to_torch(synth.make_batch(bs=3, K=7, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=90 + i, opt_holes=(i % 2),
+                                             ignore_rank_frac=0.0)) for i in range(4)]
+
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, global_step=None):
+            self.rows.append((tag, float(value), global_step))
+    w = Writer()
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    U.train_epoch(0, model, opt, sched, loader, w, True, args, None)
+    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert float((after - before).abs().max()) > 0
+    tags = {t for t, _, _ in w.rows}
+    assert {"learning_rate/train", "loss/train", "loss/vision", "loss/language", "loss/ranking", "accuracy/ranking"} <= tags
+    assert sorted({s for _, _, s in w.rows}) == [0, 1, 2, 3]
+    assert all(np.isfinite(v) for _, v, _ in w.rows), [r for r in w.rows if not np.isfinite(r[1])]
+
+    sd = {k: v.cpu() for k, v in model.state_dict().items()
+          if not (k.startswith("vil_logit") or k.startswith("judge") or "orientation_embeddings" in k)}
+    assert len(sd) < len(model.state_dict())
+    sd["some.unexpected.key"] = torch.zeros(3)
+    path = tmp_path / "pretrained_model.bin"
+    torch.save(sd, path)
+    cfg = BertConfig(**cfg_dict("micro.json", **ZERO_DROP))
+    cfg.args = args
+    torch.manual_seed(123)
+    m2 = Lily.from_pretrained(str(path), cfg, default_gpu=False, dropout_prob=0.0).to(dev)
+    s2 = m2.state_dict()
+    for k, v in model.state_dict().items():
+        if k in sd:
+            assert torch.equal(s2[k], v), k
+    assert not torch.equal(s2["vil_logit.weight"], model.state_dict()["vil_logit.weight"])       # stayed at its own initialisation
