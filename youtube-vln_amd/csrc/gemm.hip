@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct Plan { int tile; int splits; int streamk; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
 constexpr int SK_GRID = 512;                 // stream-K workgroups: two per CU, all resident
 
-static double plan_cost(int M, int N, int K, int tile, int sp) {
+static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0) {
     // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
     static const double tk[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
@@ -648,7 +648,9 @@ static double plan_cost(int M, int N, int K, int tile, int sp) {
     // the 4-wave tiles only reach their rate with 2-3 blocks co-resident on a CU (one block = one wave per SIMD)
     const double need = tile == 1 ? 2.0 : tile == 2 ? 3.0 : 1.0, per_cu = std::max(1.0, blocks / 256.0);
     const double occ = per_cu < need ? need / per_cu : 1.0;
-    double t = waves * (tfix[tile] + (double)(kchunk / BK) * tk[tile] * occ);
+    // fused activations read / write a second matrix in the epilogue: dearer for the 256-row tiles (64-128 KB per workgroup, no overlap)
+    const double tf = tfix[tile] + ((tile >= 3 && epilogue != YTVLN_EPI_NONE) ? 10.0 : 0.0);
+    double t = waves * (tf + (double)(kchunk / BK) * tk[tile] * occ);
     if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / 3.0e6;     // us: launch + bytes at ~3 TB/s
     return t;
 }
@@ -667,8 +669,9 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         const int smax = (tile == 0 && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
-            const double t = plan_cost(M, N, K, tile, sp);
-            if (t < best_t * 0.98) { best_t = t; best = {tile, sp, 0}; }       // fewer splits / larger tiles win near-ties
+            const double t = plan_cost(M, N, K, tile, sp, epilogue);
+            // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
+            if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp, 0}; }
         }
     }
     // stream-K over 128x128 tiles (gemm_streamk_kernel): every one of the 512 resident workgroups gets the same number of k-tiles, any
