@@ -88,6 +88,10 @@ int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, 
  *   ytvln_gemm_bf16_nt:  C[M,N] (+)= A[M,K] . B[N,K]^T with A, B staged as above (K = the padded contraction length, % 64 == 0);
  *     bias / aux / epilogue / beta / workspace exactly as ytvln_gemm_f32 (workspace sized by ytvln_gemm_workspace_elems(M,N,K/2,epi)). */
 int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpose, uint16_t* out, int64_t ldo, void* stream);
+/* both stagings of one matrix in one pass (x read once): out_plain [rows][ld_plain] and out_t [cols][ld_t] -- a gradient dY is the A operand of
+ * the input-gradient GEMM in the first form and of the weight-gradient GEMM in the second */
+int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain, uint16_t* out_t, int64_t ld_t,
+                         void* stream);
 int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                        float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
                        int64_t workspace_elems, void* stream);

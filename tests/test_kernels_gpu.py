@@ -750,3 +750,16 @@ print("STREAMK_OK")
     env = dict(os.environ, YTVLN_GEMM_STREAMK="2")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "STREAMK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("rows,cols", [(256, 128), (300, 200), (65, 1601), (4480, 768), (70, 30)])
+def test_cast_bf16_dual_equals_separate_stagings(dev, lib, rows, cols):
+    """One pass producing both bf16 stagings == the plain and the transposing staging kernels, bit for bit (zero tails included)."""
+    from ytvln import ops
+    x = torch.randn(rows, cols + 8, device=dev)[:, :cols]                    # a strided view: leading dimension cols + 8
+    (p, ldp), (t, ldt) = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
+    p2, ldp2 = ops._stage_bf16(x, x.stride(0), rows, cols, False)
+    t2, ldt2 = ops._stage_bf16(x, x.stride(0), rows, cols, True)
+    assert (ldp, ldt) == (ldp2, ldt2)
+    assert torch.equal(p.view(torch.int16), p2.view(torch.int16)) and torch.equal(t.view(torch.int16), t2.view(torch.int16))
+    assert torch.equal(p[:, :cols].float(), x.bfloat16().float()) and bool((p[:, cols:] == 0).all()) and bool((t[:, rows:] == 0).all())

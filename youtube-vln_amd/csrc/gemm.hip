@@ -823,6 +823,46 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
     }
 }
 
+// Both stagings of one fp32 matrix in a single pass (a gradient dY feeds the input-gradient GEMM as [rows][cols] and the
+// weight-gradient GEMM as [cols][rows]): x is read once, 64 x 64 tiles through LDS as in cast_bf16_t_kernel.
+__global__ __launch_bounds__(256) void cast_bf16_dual_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols,
+                                                             uint16_t* __restrict__ outp, int64_t ldp, uint16_t* __restrict__ outt, int64_t ldt,
+                                                             int vec) {
+    __shared__ float tile[64][65];
+    const int tiles_c = (int)(ldp >> 6);
+    const int r0 = (blockIdx.x / tiles_c) << 6, c0 = (blockIdx.x % tiles_c) << 6;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                       // 64 rows x 16 float4
+        const int idx = tid + 256 * it, r = idx >> 4, c = (idx & 15) << 2;
+        const int gr = r0 + r, gc = c0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < rows) {
+            const float* p = x + (int64_t)gr * ldx + gc;
+            if (vec && gc + 4 <= cols) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (gc < cols) v.x = p[0];
+                if (gc + 1 < cols) v.y = p[1];
+                if (gc + 2 < cols) v.z = p[2];
+                if (gc + 3 < cols) v.w = p[3];
+            }
+            // plain staging straight from the registers (zero tail up to ldp comes with the zero-filled v)
+            *reinterpret_cast<uint2*>(outp + (int64_t)gr * ldp + gc) = make_uint2(bf16_pack(v.x, v.y), bf16_pack(v.z, v.w));
+        }
+        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                       // 64 output rows (c) x 8 groups of 8 r
+        const int idx = tid + 256 * it, c = idx >> 3, r = (idx & 7) << 3;
+        if (c0 + c < cols && r0 + r < ldt) {
+            uint4 o = make_uint4(bf16_pack(tile[r][c], tile[r + 1][c]), bf16_pack(tile[r + 2][c], tile[r + 3][c]),
+                                 bf16_pack(tile[r + 4][c], tile[r + 5][c]), bf16_pack(tile[r + 6][c], tile[r + 7][c]));
+            *reinterpret_cast<uint4*>(outt + (int64_t)(c0 + c) * ldt + r0 + r) = o;
+        }
+    }
+}
+
 static void launch_bf16(GemmArgs& g, hipStream_t s) {
     g.tiles_m = (int)cdiv(g.M, 128);
     g.tiles_n = (int)cdiv(g.N, 128);
@@ -940,6 +980,21 @@ extern "C" int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, 
         hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, rows, cols, out, ldo, vec);
     }
     YT_LAUNCH_CHECK("cast_bf16");
+    return 0;
+}
+
+extern "C" int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
+                                    uint16_t* out_t, int64_t ld_t, void* stream) {
+    YT_REQUIRE(x && out_plain && out_t && rows > 0 && cols > 0 && ldx >= cols, "cast_bf16_dual: bad argument");
+    YT_REQUIRE(ld_plain % 64 == 0 && ld_plain >= cols && ld_plain < cols + 64 && ld_t % 64 == 0 && ld_t >= rows && ld_t < rows + 64,
+               "cast_bf16_dual: leading dimensions must be the contraction lengths rounded up to 64");
+    YT_REQUIRE(((reinterpret_cast<uintptr_t>(out_plain) | reinterpret_cast<uintptr_t>(out_t)) & 15) == 0, "cast_bf16_dual: outputs must be 16-byte aligned");
+    const int vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
+    const int64_t tiles = (ld_t / 64) * (ld_plain / 64);
+    YT_REQUIRE(tiles < (1ll << 31), "cast_bf16_dual: matrix too large");
+    hipLaunchKernelGGL(cast_bf16_dual_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, out_plain, ld_plain,
+                       out_t, ld_t, vec);
+    YT_LAUNCH_CHECK("cast_bf16_dual");
     return 0;
 }
 

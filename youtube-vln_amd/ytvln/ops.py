@@ -123,8 +123,22 @@ def _stage_bf16(X: Tensor, ld: int, rows: int, cols: int, transpose: bool) -> Tu
     return out, ldo
 
 
-def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0):
-    bf16 = _MATMUL_PRECISION == "bf16" and M >= 64 and N >= 64 and K >= 64
+def _stage_bf16_dual(X: Tensor, ld: int, rows: int, cols: int):
+    """Both bf16 stagings of the fp32 matrix X [rows, cols] from ONE read: ([rows][cols->64], ld) and ([cols][rows->64], ld)."""
+    ldp, ldt = (cols + 63) // 64 * 64, (rows + 63) // 64 * 64
+    plain = torch.empty((rows, ldp), dtype=torch.bfloat16, device=X.device)
+    trans = torch.empty((cols, ldt), dtype=torch.bfloat16, device=X.device)
+    call("ytvln_cast_bf16_dual", _ptr(X), ld, rows, cols, _ptr(plain), ldp, _ptr(trans), ldt, _stream())
+    return (plain, ldp), (trans, ldt)
+
+
+def _bf16_eligible(M: int, N: int, K: int) -> bool:
+    return _MATMUL_PRECISION == "bf16" and M >= 64 and N >= 64 and K >= 64
+
+
+def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, A_staged=None):
+    """`A_staged` = (bf16 tensor [M][K->64], ld): op(A) already staged by the caller (bf16 mode only; see _stage_bf16_dual)."""
+    bf16 = _bf16_eligible(M, N, K)
     Kw = (K + 63) // 64 * 32 if bf16 else K        # contraction length in 4-byte words, as the split-K planner counts it
     key = (M, N, Kw, epi)
     need = _WS_CACHE.get(key)
@@ -132,7 +146,10 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
         need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, Kw, epi))
     ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
     if bf16:
-        Ab, la = _stage_bf16(A, lda, K, M, True) if transA else _stage_bf16(A, lda, M, K, False)       # -> [M][Kp]
+        if A_staged is not None:
+            Ab, la = A_staged
+        else:
+            Ab, la = _stage_bf16(A, lda, K, M, True) if transA else _stage_bf16(A, lda, M, K, False)       # -> [M][Kp]
         Bb, lb = _stage_bf16(B, ldb, N, K, False) if transB else _stage_bf16(B, ldb, K, N, True)       # -> [N][Kp]
         call("ytvln_gemm_bf16_nt", _ptr(Ab), la, _ptr(Bb), lb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, M, N, la, epi, float(beta),
              _ptr(ws), need, _stream())
@@ -356,15 +373,18 @@ class LinearFn(torch.autograd.Function):
         else:
             dy, ldy, flags, _ = _rows_of_grad(dy, M, N)
         dx = dw = db = None
+        st_p = st_t = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _bf16_eligible(M, K, N) and _bf16_eligible(N, K, M):
+            st_p, st_t = _stage_bf16_dual(dy, ldy, M, N)          # dY read once for both of its roles
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags)
+            _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags, A_staged=st_p)
             dx = dx.view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
             dw = _direct_grad(ctx.targets, (N, K))
             if dw is None:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags)
+            _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, ldy, out=_direct_grad(ctx.btargets, (N,)))
         return dx, dw, db, None
@@ -405,21 +425,24 @@ class FFNFn(torch.autograd.Function):
             dy = dy.contiguous()
         dev = dy.device
         dz = torch.empty((M, I), dtype=torch.float32, device=dev)
-        _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU)   # dH * gelu'(z)
+        dual = _bf16_eligible(M, I, N) and _bf16_eligible(N, I, M) and _bf16_eligible(M, K, I) and _bf16_eligible(I, K, M)
+        sy_p, sy_t = _stage_bf16_dual(dy, N, M, N) if dual else (None, None)
+        _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU, A_staged=sy_p)   # dH * gelu'(z)
         dw2 = _direct_grad(ctx.targets[1], (N, I))
         if dw2 is None:
             dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
-        _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M)
+        _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t)
+        sz_p, sz_t = _stage_bf16_dual(dz, I, M, I) if dual else (None, None)
         db2 = colsum(dy, M, N, N, out=_direct_grad(ctx.targets[3], (N,)))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I)
+            _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I, A_staged=sz_p)
             dx = dx.view(ctx.in_shape)
         dw1 = _direct_grad(ctx.targets[0], (I, K))
         if dw1 is None:
             dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
-        _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M)
+        _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t)
         db1 = colsum(dz, M, I, I, out=_direct_grad(ctx.targets[2], (I,)))
         return dx, dw1, db1, dw2, db2
 
