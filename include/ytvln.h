@@ -78,6 +78,11 @@ int ytvln_colsum_by_index_f32(const float* x, int64_t ldx, const float* idx_f32,
  * padding_idx (vilbert.py:225-227, 249). */
 int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int M, int H, float* table_grad,
                                int64_t skip_idx, void* stream);
+/* Deterministic form for repeated indices (word-embedding gradient, BertEmbeddings backward, vilbert.py:219-256): `sorted_idx` = the
+ * indices in ascending order (stable sort), `perm` = the source row of each sorted position.  One wave owns each run of equal indices:
+ * no atomics, fixed summation order -> bit-reproducible training steps. */
+int ytvln_scatter_add_rows_sorted_f32(const float* x, int64_t ldx, const int64_t* sorted_idx, const int64_t* perm, int M, int H,
+                                      float* table_grad, int64_t skip_idx, void* stream);
 
 /* Mixed-precision variant of the dense projections (BASELINE config 5: "bf16 MFMA path"): fp32 tensors everywhere in HBM, bf16
  * operands staged per GEMM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 output and epilogue.  Opt-in (ytvln.ops

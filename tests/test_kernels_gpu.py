@@ -763,3 +763,26 @@ def test_cast_bf16_dual_equals_separate_stagings(dev, lib, rows, cols):
     assert (ldp, ldt) == (ldp2, ldt2)
     assert torch.equal(p.view(torch.int16), p2.view(torch.int16)) and torch.equal(t.view(torch.int16), t2.view(torch.int16))
     assert torch.equal(p[:, :cols].float(), x.bfloat16().float()) and bool((p[:, cols:] == 0).all()) and bool((t[:, rows:] == 0).all())
+
+
+def test_scatter_add_rows_sorted_is_exact_and_reproducible(dev, lib):
+    """Word-embedding gradient without atomics: equals an fp64 index_add to fp32 rounding, skips the padding id, and two launches agree
+    bit for bit (the atomic kernel does not guarantee that)."""
+    from ytvln._lib import call
+    g = torch.Generator().manual_seed(3)
+    M, H, V = 4480, 768, 997
+    x = torch.randn(M, H, generator=g).to(dev)
+    ids = torch.randint(0, V, (M,), generator=g)
+    ids[::7] = 103                                      # a long run ([MASK]) and the padding id
+    ids[::11] = 0
+    ids = ids.to(dev)
+    outs = []
+    for _ in range(2):
+        tg = torch.zeros(V, H, device=dev)
+        s, perm = torch.sort(ids, stable=True)
+        call("ytvln_scatter_add_rows_sorted_f32", x.data_ptr(), H, s.data_ptr(), perm.data_ptr(), M, H, tg.data_ptr(), 0, None)
+        outs.append(tg)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(V, H, dtype=torch.float64, device=dev).index_add_(0, ids, x.double())
+    ref[0] = 0
+    assert float((outs[0].double() - ref).abs().max()) < 1e-4 and float(outs[0][0].abs().max()) == 0.0

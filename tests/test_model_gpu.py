@@ -315,9 +315,10 @@ def test_graph_replay_equals_eager(dev, lib):
         finals.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
         losses.append(float(loss))
         assert all(opt.state[p]["step"] == 5 for p in model.parameters() if p in opt.state and "step" in opt.state[p])
-    assert abs(losses[0] - losses[1]) < 1e-6, losses
-    # (not bit-equal: the word-embedding gradient is an atomic scatter-add whose summation order varies run to run)
-    assert float((finals[0] - finals[1]).abs().max()) < 2e-6, float((finals[0] - finals[1]).abs().max())
+    # every kernel on the path sums in a fixed order (the word-embedding gradient included: sorted runs, no atomics), so replaying the
+    # graph reproduces the eager launches BIT FOR BIT
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
 
 
 def test_save_resume_and_eval_loops(dev, lib, tmp_path):

@@ -283,6 +283,30 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     }
 }
 
+// Deterministic variant for repeated indices (the word-embedding gradient: a token id occurs many times in a batch): the caller passes
+// the indices SORTED (stable) with the permutation that sorted them; the wave that sits on the first position of a run of equal
+// indices walks the run in order, accumulates in registers and owns the table row -- no atomics, a fixed summation order.
+__global__ __launch_bounds__(256) void scatter_add_rows_sorted_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                      const int64_t* __restrict__ sorted_idx, const int64_t* __restrict__ perm,
+                                                                      int M, int H, float* __restrict__ tg, int64_t skip) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H4 = H >> 2;
+    for (int i = blockIdx.x * 4 + wave; i < M; i += gridDim.x * 4) {
+        const int64_t k = sorted_idx[i];
+        if (k == skip || (i > 0 && sorted_idx[i - 1] == k)) continue;          // not the head of a run
+        for (int c0 = 0; c0 < H4; c0 += 64) {
+            const int c = c0 + lane;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < H4)
+                for (int j = i; j < M && sorted_idx[j] == k; ++j) acc = f4add(acc, reinterpret_cast<const float4*>(x + perm[j] * ldx)[c]);
+            if (c < H4) {
+                float4* dst = reinterpret_cast<float4*>(tg + k * (int64_t)H) + c;
+                *dst = f4add(*dst, acc);
+            }
+        }
+    }
+}
+
 // out[j, :] = x[idx[j], :]   (idx < 0 -> zeros).  Row gather for the loss-aware heads (only rows carrying a target go through
 // the 30522-way / 1601-way decoders); its backward is scatter_add_rows_kernel.
 // Work unit = one 1024-float piece of one output row (a wave moves it as 4 x 16 bytes per lane), so short rows (hidden states in front
@@ -480,6 +504,17 @@ extern "C" int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M, 4), 4096)), dim3(256), 0,
                        as_stream(stream), x, ldx, idx, M, H, table_grad, skip_idx);
     YT_LAUNCH_CHECK("scatter_add_rows");
+    return 0;
+}
+
+extern "C" int ytvln_scatter_add_rows_sorted_f32(const float* x, int64_t ldx, const int64_t* sorted_idx, const int64_t* perm, int M, int H,
+                                                 float* table_grad, int64_t skip_idx, void* stream) {
+    YT_REQUIRE(x && sorted_idx && perm && table_grad && H > 0 && H % 4 == 0 && ldx % 4 == 0, "scatter_add_rows_sorted: bad argument (H, ldx multiples of 4)");
+    YT_REQUIRE(al16(x) && al16(table_grad), "scatter_add_rows_sorted: pointers must be 16-byte aligned");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_sorted_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M, 4), 4096)), dim3(256), 0, as_stream(stream), x,
+                       ldx, sorted_idx, perm, M, H, table_grad, skip_idx);
+    YT_LAUNCH_CHECK("scatter_add_rows_sorted");
     return 0;
 }
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
     "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],
     "ytvln_gather_rows_f32": [P, I64, P, I32, I32, P, P],
+    "ytvln_scatter_add_rows_sorted_f32": [P, I64, P, P, I32, I32, P, I64, P],
     "ytvln_randomize_tokens": [P, P, I64, I32, I64, P, P, P, I64, P, P, P],
     "ytvln_randomize_regions": [P, I64, P, P, I64, I32, I32, P, P, I64, P, P, P],
     "ytvln_attn_fwd_bf16": [P, I64, P, I64, P, I64, P, P, I64, P, I32, I32, I32, I32, I32, F32, F32, P, I64, P],

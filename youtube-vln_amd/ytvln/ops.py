@@ -548,7 +548,9 @@ class TextEmbedFn(torch.autograd.Function):
         ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
         dev = ds.device
         dword = torch.zeros(wshape, dtype=torch.float32, device=dev)
-        call("ytvln_scatter_add_rows_f32", _ptr(ds), H, _ptr(ids), rows, H, _ptr(dword), 0, _stream())   # padding_idx = 0
+        # token ids repeat inside a batch: sorted (stable) so that one wave owns each id's run -- no atomics, reproducible sums
+        sorted_ids, perm = torch.sort(ids.reshape(-1), stable=True)
+        call("ytvln_scatter_add_rows_sorted_f32", _ptr(ds), H, _ptr(sorted_ids), _ptr(perm), rows, H, _ptr(dword), 0, _stream())   # padding_idx = 0
         dpos = torch.zeros(pshape, dtype=torch.float32, device=dev)
         dpos[:T] = colsum(ds, N, T * H, T * H).view(T, H)
         if tt is None:
