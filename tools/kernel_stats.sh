@@ -11,6 +11,6 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time {tot/1e6:.1f} ms over the traced run (6 steps)")
-for r in rows[:22]:
+for r in rows[:int(__import__("os").environ.get("TOPN", "22"))]:
     print(f'{float(r["TotalDurationNs"])/6e6:8.2f} ms/step {float(r["Percentage"]):5.1f}% calls/step {int(r["Calls"])/6:7.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {r["Name"][:90]}')
 PYEOF

@@ -863,11 +863,28 @@ __global__ __launch_bounds__(256) void cast_bf16_dual_kernel(const float* __rest
     }
 }
 
+// bf16 tiles.  With 8x shorter matrix time the operand path (LDS-DMA issue, ~1 KiB per wave instruction) is what a workgroup waits
+// for, so the 256x256 tile (half the operand bytes per flop, one workgroup per CU) wins wherever it fills the chip about as well as
+// 128x128 does: +15-19 % on 129024x1024x1024 / 16128x3072x1024, +10 % on 4480x3072x768, level on 16128x1024x1024 (measured,
+// kernel alone).  Split-K launches and fused activations (their epilogue is exposed with one workgroup per CU) stay on 128x128.
+static bool bf16_big_tile(const GemmArgs& g) {
+    static const int force = getenv("YTVLN_BF16_TILE") ? atoi(getenv("YTVLN_BF16_TILE")) : -1;      // experiment knob: 0 / 4
+    if (force >= 0) return force == 4 && g.M >= 256 && g.N >= 256;
+    if (g.splits > 1 || g.epilogue != YTVLN_EPI_NONE || g.M < 256 || g.N < 256) return false;
+    const double b128 = (double)(cdiv(g.M, 128) * cdiv(g.N, 128)), b256 = (double)(cdiv(g.M, 256) * cdiv(g.N, 256));
+    const double e128 = b128 / (ceil(b128 / 512.0) * 512.0), e256 = b256 / (ceil(b256 / 256.0) * 256.0);
+    return b256 >= 200.0 && e256 >= e128 - 0.05;
+}
+
 static void launch_bf16(GemmArgs& g, hipStream_t s) {
-    g.tiles_m = (int)cdiv(g.M, 128);
-    g.tiles_n = (int)cdiv(g.N, 128);
+    const bool big = bf16_big_tile(g);
+    const int bt = big ? 256 : 128;
+    g.tiles_m = (int)cdiv(g.M, bt);
+    g.tiles_n = (int)cdiv(g.N, bt);
     g.ntiles = g.tiles_m * g.tiles_n;
-    hipLaunchKernelGGL((gemm_dma_kernel<128, 128, true, true, 8, 32, 2, 4, true>), dim3(g.ntiles * g.splits), dim3(512), 0, s, g);
+    const dim3 grid(g.ntiles * g.splits);
+    if (big) hipLaunchKernelGGL((gemm_dma_kernel<256, 256, true, true, 8, 32, 2, 2, true>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, true, true, 8, 32, 2, 4, true>), grid, dim3(512), 0, s, g);
 }
 
 }  // namespace ytvln
