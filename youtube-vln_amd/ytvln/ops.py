@@ -6,6 +6,7 @@ libytvln.so.  All wrappers require CUDA(HIP) fp32 tensors -- there is no CPU or 
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -132,12 +133,17 @@ def _stage_bf16_dual(X: Tensor, ld: int, rows: int, cols: int):
     return (plain, ldp), (trans, ldt)
 
 
+_FWD_DUAL = os.environ.get("YTVLN_BF16_FWD_DUAL", "1") != "0"      # experiment knob: 0 -> re-stage the inputs in backward
+
+
 def _bf16_eligible(M: int, N: int, K: int) -> bool:
     return _MATMUL_PRECISION == "bf16" and M >= 64 and N >= 64 and K >= 64
 
 
-def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, A_staged=None):
-    """`A_staged` = (bf16 tensor [M][K->64], ld): op(A) already staged by the caller (bf16 mode only; see _stage_bf16_dual)."""
+def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, A_staged=None,
+          B_staged=None):
+    """`A_staged` / `B_staged` = (bf16 tensor [M][K->64] / [N][K->64], ld): the operand already staged by the caller (bf16 mode only;
+    see _stage_bf16_dual)."""
     bf16 = _bf16_eligible(M, N, K)
     Kw = (K + 63) // 64 * 32 if bf16 else K        # contraction length in 4-byte words, as the split-K planner counts it
     key = (M, N, Kw, epi)
@@ -150,7 +156,10 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
             Ab, la = A_staged
         else:
             Ab, la = _stage_bf16(A, lda, K, M, True) if transA else _stage_bf16(A, lda, M, K, False)       # -> [M][Kp]
-        Bb, lb = _stage_bf16(B, ldb, N, K, False) if transB else _stage_bf16(B, ldb, K, N, True)       # -> [N][Kp]
+        if B_staged is not None:
+            Bb, lb = B_staged
+        else:
+            Bb, lb = _stage_bf16(B, ldb, N, K, False) if transB else _stage_bf16(B, ldb, K, N, True)   # -> [N][Kp]
         call("ytvln_gemm_bf16_nt", _ptr(Ab), la, _ptr(Bb), lb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, M, N, la, epi, float(beta),
              _ptr(ws), need, _stream())
         return
@@ -349,7 +358,12 @@ class LinearFn(torch.autograd.Function):
         else:
             y, ldy = torch.empty((M, N), dtype=torch.float32, device=x.device), N
         z = torch.empty_like(y) if (epi == EPI_GELU and need_grad) else None
-        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
+        # bf16 mode: the input is read ONCE for both of its bf16 roles -- [M][K] for this GEMM and [K][M] (kept for backward) for
+        # the weight-gradient GEMM -- instead of a second fp32 pass over it in backward
+        st_p = ctx.x_t = None
+        if _FWD_DUAL and ctx.needs_input_grad[1] and _bf16_eligible(M, N, K) and _bf16_eligible(N, K, M):
+            st_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K)
+        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi, A_staged=st_p)
         ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
         ctx.in_shape = x.shape
         ctx.targets = _targets_of(weight)
@@ -384,7 +398,8 @@ class LinearFn(torch.autograd.Function):
             dw = _direct_grad(ctx.targets, (N, K))
             if dw is None:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t)
+            _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t, B_staged=ctx.x_t)
+            ctx.x_t = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, ldy, out=_direct_grad(ctx.btargets, (N,)))
         return dx, dw, db, None
@@ -406,9 +421,14 @@ class FFNFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         h = torch.empty((M, I), dtype=torch.float32, device=x.device)
         z = torch.empty_like(h) if need_grad else None
-        _gemm(x2, lda, 0, w1, w1.stride(0), 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU)
+        # bf16 mode: x and h are each read once for both bf16 roles (this GEMM's [M][K] operand, the weight-gradient GEMM's [K][M])
+        dual = _FWD_DUAL and need_grad and _bf16_eligible(M, I, K) and _bf16_eligible(I, K, M) and _bf16_eligible(M, N, I) and _bf16_eligible(N, I, M)
+        sx_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K) if dual else (None, None)
+        _gemm(x2, lda, 0, w1, w1.stride(0), 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU, A_staged=sx_p)
+        del sx_p
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2)
+        sh_p, ctx.h_t = _stage_bf16_dual(h, I, M, I) if dual else (None, None)
+        _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2, A_staged=sh_p)
         ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
         ctx.targets = (_targets_of(w1), _targets_of(w2), _targets_of(b1), _targets_of(b2))
         ctx.save_for_backward(x2, w1, w2, z, h)
@@ -431,7 +451,8 @@ class FFNFn(torch.autograd.Function):
         dw2 = _direct_grad(ctx.targets[1], (N, I))
         if dw2 is None:
             dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
-        _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t)
+        _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t, B_staged=ctx.h_t)
+        ctx.h_t = None
         sz_p, sz_t = _stage_bf16_dual(dz, I, M, I) if dual else (None, None)
         db2 = colsum(dy, M, N, N, out=_direct_grad(ctx.targets[3], (N,)))
         dx = None
@@ -442,7 +463,8 @@ class FFNFn(torch.autograd.Function):
         dw1 = _direct_grad(ctx.targets[0], (I, K))
         if dw1 is None:
             dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
-        _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t)
+        _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t, B_staged=ctx.x_t)
+        ctx.x_t = None
         db1 = colsum(dz, M, I, I, out=_direct_grad(ctx.targets[2], (I,)))
         return dx, dw1, db1, dw2, db2
 
