@@ -23,6 +23,7 @@ import sys
 import time
 import types
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver (multi-process GPU runs)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "youtube-vln_amd"), ROOT):
     if p not in sys.path:

@@ -869,8 +869,8 @@ __global__ __launch_bounds__(256) void cast_bf16_dual_kernel(const float* __rest
 // kernel alone).  Split-K launches and fused activations (their epilogue is exposed with one workgroup per CU) stay on 128x128.
 static bool bf16_big_tile(const GemmArgs& g) {
     static const int force = getenv("YTVLN_BF16_TILE") ? atoi(getenv("YTVLN_BF16_TILE")) : -1;      // experiment knob: 0 / 4
-    if (force >= 0) return force == 4 && g.M >= 256 && g.N >= 256;
-    if (g.splits > 1 || g.epilogue != YTVLN_EPI_NONE || g.M < 256 || g.N < 256) return false;
+    if (force == 0 || force == 4) return force == 4 && g.M >= 256 && g.N >= 256;
+    if (g.splits > 1 || (g.epilogue != YTVLN_EPI_NONE && force != 5) || g.M < 256 || g.N < 256) return false;
     const double b128 = (double)(cdiv(g.M, 128) * cdiv(g.N, 128)), b256 = (double)(cdiv(g.M, 256) * cdiv(g.N, 256));
     const double e128 = b128 / (ceil(b128 / 512.0) * 512.0), e256 = b256 / (ceil(b256 / 256.0) * 256.0);
     return b256 >= 200.0 && e256 >= e128 - 0.05;

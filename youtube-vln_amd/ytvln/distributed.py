@@ -48,6 +48,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int]:
     if world <= 1:
         return 0, 1
     if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the only mode this driver supports)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
