@@ -61,9 +61,10 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="auto|on: replay the step from hipGraphs (1 GPU: one graph; N GPUs: two graphs around the RCCL all-reduce), falling back to eager launches if capture fails; off: eager launches")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
-                    help="fp32 (default, the headline: the reference's arithmetic) or bf16: dense projections on bf16 MFMA operands "
-                         "with fp32 accumulation, everything else fp32 (BASELINE configs[4])")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp32x3"], default="fp32",
+                    help="fp32 (default, the headline: the reference's arithmetic on the fp32 matrix instruction); bf16: dense projections "
+                         "on bf16 MFMA operands with fp32 accumulation, everything else fp32 (BASELINE configs[4]); fp32x3: fp32 operands, "
+                         "each value split exactly into three bf16 terms in registers, six bf16 MFMAs per product (fp32-level error)")
     ap.add_argument("--h2d", choices=["off", "serial", "overlap", "compact"], default="off",
                     help="also move the batch from pinned host memory to HBM every step (NOT the headline: `value` is quoted with inputs "
                          "resident in HBM): serial = on the compute stream before the step, overlap = on a copy stream under the previous step, "
@@ -382,7 +383,9 @@ def main():
         "metric": "pretrain samples/sec (traj-instr pairs)", "value": round(value, 3), "unit": "pairs/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * elapsed / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.precision == "fp32" else "bf16 MFMA operands, f32 accumulate / activations / master weights", "data": "synthetic",
+        "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate / activations / master weights",
+                  "fp32x3": "f32 operands split exactly into 3 bf16 terms in registers, 6 bf16 MFMAs per product, f32 accumulate (projections); "
+                            "f32 everywhere else"}[a.precision], "data": "synthetic",
         "config": {"workload": a.workload, **({"dist_backend": os.environ["YTVLN_DIST_BACKEND"]} if "YTVLN_DIST_BACKEND" in os.environ else {}), "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
                    "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
                    "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
@@ -390,12 +393,14 @@ def main():
                    "execution": execution, "heads": "loss-aware rows (extension)" if a.loss_aware_heads else "all rows (reference)"},
         "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
         "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / a.steps, 2),
+        "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
     }
     if a.h2d != "off":
         out["h2d"] = {"mode": a.h2d, "bytes_per_step": h2d_bytes, "note": "value INCLUDES the host->HBM upload of the batch; not the headline"}
-    if "full" in a.workload and T == 80 and frames * boxes == 288 and not a.loss_aware_heads and a.precision == "fp32":   # (FLOP count is the full-decode one)
+    if "full" in a.workload and T == 80 and frames * boxes == 288 and not a.loss_aware_heads and a.precision in ("fp32", "fp32x3"):   # (FLOP count is the full-decode one)
         out["model_tflops"] = round(value * TRAIN_GFLOP_PER_PAIR / 1000.0, 2)
-        out["model_mfma_frac"] = round(value / world * TRAIN_GFLOP_PER_PAIR / 1000.0 / PEAK_F32_MFMA_TFLOPS, 4)
+        if a.precision == "fp32":
+            out["model_mfma_frac"] = round(value / world * TRAIN_GFLOP_PER_PAIR / 1000.0 / PEAK_F32_MFMA_TFLOPS, 4)
     if not a.no_kernel_timing and timer.records:
         ms, flop, n, shapes = timer.summary()
         ach = flop / (ms * 1e-3) / 1e12
@@ -406,9 +411,11 @@ def main():
             traffic_note = "profiles/round1_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
         except (OSError, KeyError, ValueError):
             pass
-        peak = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        kname = "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "fp32" else \
-            "ytvln::gemm_dma_kernel<bf16> (v_mfma_f32_32x32x16_bf16) + bf16 operand staging kernels"
+        # fp32x3: six bf16 matrix instructions per algorithmic product -> the ceiling for algorithmic FLOPs is the bf16 peak / 6
+        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32x3": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}[a.precision]
+        kname = {"fp32": "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)",
+                 "bf16": "ytvln::gemm_dma_kernel<bf16> (v_mfma_f32_32x32x16_bf16) + bf16 operand staging kernels",
+                 "fp32x3": "ytvln::gemm_dma_kernel<X3> (6 x v_mfma_f32_32x32x16_bf16 per product; peak = bf16 dense peak / 6)"}[a.precision]
         if a.precision != "fp32":
             traffic, traffic_note = None, None
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),

@@ -54,6 +54,10 @@ enum {
  *   lda (rounded to 32 for a K-contiguous A with B = [K,N]; to 4 for an M-contiguous A).  It lets the 30522- and 1601-wide
  *   logit gradients (vilbert.py:906, 968 backward) use the LDS-DMA main loop although 30522 % 32 != 0. */
 #define YTVLN_GEMM_A_ZERO_PADDED 1
+/* opt-in: every fp32 operand value is split exactly into three bf16 terms in registers and each product is accumulated in fp32
+ * from the six largest cross terms on the bf16 matrix instruction (error per product ~ one fp32 rounding; LDS-DMA path only,
+ * ignored by the generic kernel and by stream-K launches) */
+#define YTVLN_GEMM_SPLIT_BF16X3 2
 int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
 /* Introspection (host only, no GPU work): the tile shape and split count the launch planner picks for an aligned problem of this size
  * (transA = 1: M-contiguous A, which excludes the 256-row tiles).  Used by tests and by tools/ to explain a measurement. */

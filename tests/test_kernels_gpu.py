@@ -566,6 +566,47 @@ def test_gemm_bf16_staged(dev, lib, M, N, K, ta, tb, epi):
         assert float((C.double().cpu() - full).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,epi", [
+    (384, 256, 256, 0, 1, 0), (300, 200, 96, 0, 0, 0), (300, 200, 96, 1, 0, 0), (260, 132, 64, 1, 1, 0), (512, 384, 256, 0, 1, 1),
+    (128, 256, 4096, 1, 0, 0), (1000, 520, 160, 0, 1, 3),
+    (3600, 3592, 128, 0, 1, 0), (4096, 1024, 512, 0, 0, 0), (3080, 1024, 96, 0, 1, 1)])      # the last three: 256-row tiles
+def test_gemm_fp32_split_bf16x3(dev, lib, M, N, K, ta, tb, epi):
+    """fp32x3 projections (YTVLN_GEMM_SPLIT_BF16X3): fp32 operands, every value split exactly into three bf16 terms in registers,
+    six bf16 MFMAs per product with fp32 accumulation.  Bar: the SAME as the native fp32 MFMA path -- max error against the fp64
+    product within 4e-6 * sqrt(K) * |a||b| scale -- and no worse than 2x the native kernel's own error on the same inputs; the
+    result must differ from the native kernel's somewhere (it really is a different instruction stream, no silent fallback)."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux_in = torch.randn(M, N, generator=g).to(dev)
+    outs = {}
+    for mode in ("fp32", "fp32x3"):
+        C = torch.empty(M, N, device=dev)
+        aux = aux_in.clone() if epi == 3 else (torch.empty(M, N, device=dev) if epi else None)
+        ops.set_matmul_precision(mode)
+        try:
+            ops._gemm(A, A.stride(0), ta, B, B.stride(0), tb, C, N, M, N, K, bias=None if epi == 3 else bias, aux=aux, ldaux=N, epi=epi)
+        finally:
+            ops.set_matmul_precision("fp32")
+        outs[mode] = C.double().cpu()
+    ref = (A.t() if ta else A).double().cpu() @ (B if tb else B.t()).double().cpu().t()
+    if epi == 3:        # EPI_MUL_DGELU: C = product * gelu'(aux)
+        z = aux_in.double().cpu()
+        ref = ref * (0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * torch.pi) ** 0.5)
+    else:
+        ref = ref + bias.double().cpu()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+    e_native = float((outs["fp32"] - ref).abs().max())
+    e_split = float((outs["fp32x3"] - ref).abs().max())
+    tol = 4e-6 * (K ** 0.5) * 4.0 + 1e-5
+    assert e_split < tol, (e_split, tol)
+    assert e_split < 2.0 * e_native + 1e-6, (e_split, e_native)
+    assert not torch.equal(outs["fp32"], outs["fp32x3"]), "fp32x3 reproduced the native kernel bit for bit: the split path did not run"
+
+
 def test_edge_cases_and_loud_failures(dev, lib):
     """Empty problems are no-ops; illegal arguments raise with the library's message (no silent fallback of any kind)."""
     from ytvln import ops

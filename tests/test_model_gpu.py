@@ -458,6 +458,29 @@ def test_g2_full_model_bf16_projections(dev, lib):
     assert not bad, bad[:5]
 
 
+def test_g2_g4_full_model_fp32x3_meets_the_fp32_bar(dev, lib):
+    """The opt-in fp32x3 projections (fp32 operands split exactly into three bf16 terms in registers, six bf16 MFMAs per product)
+    against the SAME goldens and the SAME tolerances as the native fp32 path (test_g2 / test_g4: losses within 1e-4, gradient
+    summaries, post-AdamW parameters): the mode is an fp32-level arithmetic, not a reduced-precision one."""
+    from ytvln import ops, synth
+    ops.set_matmul_precision("fp32x3")
+    try:
+        g = gold("g2_full_n7.npz")
+        args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+        model, W = build_lily(dev, "bert_base_6_layer_6_connect.json", args, seed=13)
+        batch = synth.to_torch(synth.make_batch(bs=1, K=7, T=80, frames=8, boxes=36, seed=23, ignore_rank_frac=0.0), dev)
+        check_summaries(model, W, batch, args, g, float(g["lr"]))
+        del model
+        g = gold("g4_finetune_rank.npz")
+        args = args_ns(ranking=True, traj_judge=True, pretrain=False, num_negatives=2)
+        model, W = build_lily(dev, "bert_base_6_layer_6_connect.json", args, seed=15)
+        nb = synth.make_batch(bs=2, K=6, T=80, frames=7, boxes=36, seed=25, finetune_heading=True, ignore_rank_frac=0.0)
+        nb[0][1] = -1
+        check_summaries(model, W, synth.to_torch(nb, dev), args, g, float(g["lr"]))
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
 def test_inference_rerank_shapes_match_oracle(dev, lib):
     """The re-ranking inference path (test.py:144-192) at the reference's inference shapes: 30 candidate beams per instruction,
     R = 8 viewpoints x 101 regions = 808 (not a multiple of the 32-row attention tiles), T = 60, forward only, eval mode -- on the

@@ -32,6 +32,7 @@ struct GemmArgs {
     int mnA, mnB;         // clamp extents of the operands in their M / N dimension (rounded up to 4 inside padding)
     int ktail;            // 1: the last k-tile reaches past K -> M/N-contiguous operands clamp their k rows to K-1
     int* sk_flags;        // stream-K: one arrival flag per workgroup (zeroed before the launch); partials live in ws
+    int x3;               // 1: fp32 operands split into three bf16 terms in registers, six bf16 MFMAs per product (YTVLN_GEMM_SPLIT_BF16X3)
 };
 
 constexpr int BK = 32;
@@ -349,9 +350,41 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // the k-slots of the two half-waves are any fixed, identical split for A and B).  Accumulation and epilogue stay fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool BF16 = false>
+// X3 = true ("fp32 by three bf16 terms"): the operands stay fp32 in HBM and LDS; a lane splits the eight consecutive k it owns
+// (two 16-byte fragments) EXACTLY into x = hi + mid + lo, each term a bf16 (8 significant bits: hi = the top 16 bits of x,
+// mid = the top 16 bits of x - hi, lo = x - hi - mid, which has at most 8 significant bits left), and the product a.b is
+// accumulated in fp32 from the six largest of the nine cross terms on v_mfma_f32_32x32x16_bf16:
+//     hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid        (dropped: mid.lo + lo.mid + lo.lo <= 2^-23 |a||b|)
+// i.e. the error per product is of the order of one fp32 rounding of that product, at 48 instead of 128 MFMA passes per 16 k.
+struct Split3 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ uint32_t top_halves(float odd, float even) {      // {bf16 bits of odd, bf16 bits of even}, truncated
+    return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
+}
+__device__ __forceinline__ Split3 split3(const float4 u, const float4 v) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);          // exact: the low 16 bits of the significand
+        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);        // exact: its low 8 bits
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = top_halves(x[2 * e + 1], x[2 * e]);
+        m[e] = top_halves(r1[2 * e + 1], r1[2 * e]);
+        l[e] = top_halves(r2[2 * e + 1], r2[2 * e]);
+    }
+    Split3 s;
+    s.hi = __builtin_bit_cast(bf16x8, h); s.mid = __builtin_bit_cast(bf16x8, m); s.lo = __builtin_bit_cast(bf16x8, l);
+    return s;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g) {
     static_assert(!BF16 || (A_KC && B_KC && KB == 32), "bf16 operands are staged K-contiguous");
+    static_assert(!(BF16 && X3), "the split applies to fp32 operands");
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
     constexpr int WM = NW / 2;                         // waves along m (x 2 along n)
@@ -424,6 +457,49 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         const float* As = smem + st_out * STAGE;
         const float* Bs = As + SA;
         st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
+        if constexpr (X3) {
+            // Software pipeline inside the k-tile: the split of the NEXT operand fragments (VALU) is written next to the six-MFMA groups
+            // of the current ones, so that the matrix pipe and the vector ALU of a SIMD work at the same time (5.5 VALU ops per value).
+            constexpr int NSP = NG / 2;                        // 16 k per step: this lane's k-groups 2sp and 2sp+1 (8 consecutive k)
+            auto fa = [&](int i, int sp) { return split3(TA::frag(As, wm0, i, l31, half, 2 * sp), TA::frag(As, wm0, i, l31, half, 2 * sp + 1)); };
+            auto fb = [&](int j, int sp) { return split3(TB::frag(Bs, wn0, j, l31, half, 2 * sp), TB::frag(Bs, wn0, j, l31, half, 2 * sp + 1)); };
+            Split3 a[TM], an[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = fa(i, 0);
+            Split3 b = fb(0, 0), bn = b;
+#pragma unroll
+            for (int sp = 0; sp < NSP; ++sp) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool more = sp + 1 < NSP;
+                    if (j + 1 < TN) bn = fb(j + 1, sp);
+                    else if (more) bn = fb(0, sp + 1);
+                    if (more) {                                // the next step's A fragments, spread over the middle groups
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            if ((TN >= TM + 2 && j == i + 1) || (TN < TM + 2 && j == TN - 1)) an[i] = fa(i, sp + 1);
+                    }
+                    // term-major so that consecutive matrix instructions target different accumulators (smallest terms first)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].mid, b.mid, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].lo, b.hi, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].hi, b.lo, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].mid, b.hi, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].hi, b.mid, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].hi, b.hi, acc[i][j], 0, 0, 0);
+                    b = bn;
+                }
+                if (sp + 1 < NSP) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = an[i];
+                }
+            }
+        } else {
 #pragma unroll
         for (int sg = 0; sg < NG; ++sg) {
             float4 a[TM], b[TN];
@@ -445,6 +521,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                     }
                 }
+        }
         }
     }
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
@@ -637,10 +714,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct Plan { int tile; int splits; int streamk; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
 constexpr int SK_GRID = 512;                 // stream-K workgroups: two per CU, all resident
 
-static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0) {
+static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0, bool x3 = false) {
     // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
-    static const double tk[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
+    // us per 32-deep k-tile at the CU-exclusive rate: native fp32 MFMA | three-bf16-term form (fitted on 16128x1024x1024: the split's
+    // VALU work is shared best by the wide wave tiles -- 128x128 is VALU-bound, 256x256 matrix-bound)
+    static const double tk_f32[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tk_x3[5] = {1.61, 0.82, 0.45, 2.86, 4.94};
+    static const double tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
+    const double* tk = x3 ? tk_x3 : tk_f32;
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
     const int splits = (int)cdiv(K, kchunk);
     const double blocks = (double)(cdiv(M, bm[tile]) * cdiv(N, bn[tile])) * splits;
@@ -657,7 +738,7 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0)
 
 // big_ok: the 256-row tiles are only used with a K-contiguous A on the LDS-DMA path (an M-contiguous A needs four ds_read_b32 per
 // fragment and loses with the wide wave tiles: 121 -> 99 TFLOP/s on 30522x768x4480).
-static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool sk_ok = false) {
+static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool sk_ok = false, bool x3 = false) {
     Plan best = {0, 1, 0};
     double best_t = 1e30;
     const int force_tile = getenv("YTVLN_GEMM_TILE") ? atoi(getenv("YTVLN_GEMM_TILE")) : -1;       // experiment knobs
@@ -669,7 +750,7 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         const int smax = (tile == 0 && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
-            const double t = plan_cost(M, N, K, tile, sp, epilogue);
+            const double t = plan_cost(M, N, K, tile, sp, epilogue, x3);
             // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
             if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp, 0}; }
         }
@@ -679,7 +760,7 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
     // partial-tile round trip and the second pipeline fill, all workgroups in lock-step: 0.97x / 0.95x of the best ordinary plan.
     // Kept as an opt-in (YTVLN_GEMM_STREAMK=1: when the model predicts a win, =2: whenever legal); off by default.
     static const int sk_on = getenv("YTVLN_GEMM_STREAMK") ? atoi(getenv("YTVLN_GEMM_STREAMK")) : 0;
-    if (sk_ok && sk_on && force_tile < 0 && force_sp < 0 && K % BK == 0) {
+    if (sk_ok && !x3 && sk_on && force_tile < 0 && force_sp < 0 && K % BK == 0) {
         const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), nkt = K / BK;
         if (tiles >= 96 && tiles * nkt >= 4 * SK_GRID) {
             const double t = 35.0 + (double)cdiv(tiles * nkt, 256) * 2.3;
@@ -717,14 +798,25 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.ntiles = g.tiles_m * g.tiles_n;
     dim3 grid(g.ntiles * g.splits), block(256);
     if (g.fast) {
-#define YT_DMA(NW, KB, NS, WPS)                                                                                                        \
+#define YT_DMA_X(NW, KB, NS, WPS, X3V)                                                                                                 \
     do {                                                                                                                               \
         dim3 blk(NW * 64);                                                                                                             \
-        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);          \
-        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
-        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);                           \
+        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g);        \
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g); \
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g); \
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g);                         \
     } while (0)
+#define YT_DMA(NW, KB, NS, WPS) YT_DMA_X(NW, KB, NS, WPS, false)
+// the production configurations also exist in the three-bf16-term form (YTVLN_GEMM_SPLIT_BF16X3)
+#define YT_DMA_MAIN(NW, KB, NS, WPS)                  \
+    do {                                              \
+        if (g.x3) YT_DMA_X(NW, KB, NS, WPS, true);    \
+        else YT_DMA_X(NW, KB, NS, WPS, false);        \
+    } while (0)
+#ifdef YT_DEV_X3_BIG      // development builds: only the 256x256 three-term kernels are instantiated (minutes -> seconds of compile time)
+        if constexpr (BM == 256 && BN == 256) YT_DMA_X(8, 32, 2, 2, true);
+        return 0;
+#else
         static const int cfg = getenv("YTVLN_GEMM_CFG") ? atoi(getenv("YTVLN_GEMM_CFG")) : 0;
         // 128x128 tiles run 8 waves per workgroup (4 per SIMD at 2 workgroups/CU): measured 113 -> 121 TFLOP/s on
         // 16128x1024x1024 and 84 -> 105 on the split-K weight gradients versus 4 waves (barrier coupling across SIMDs).
@@ -732,25 +824,30 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
         if constexpr (BM == 256 && BN == 256) {
-            YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
+            YT_DMA_MAIN(8, 32, 2, 2);               // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
-            YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x64, one workgroup per CU
+            YT_DMA_MAIN(8, 32, 2, 2);               // 8 waves of 64x64, one workgroup per CU
         } else if constexpr (BM == 128 && BN == 128) {
-            if (cfg == 1) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
-            else if (cfg == 2 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
-            else YT_DMA(8, 32, 2, 4);
+            if (cfg == 1 && !g.x3) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
+            else if (cfg == 2 && !g.x3 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
+            else YT_DMA_MAIN(8, 32, 2, 4);
         } else {
-            YT_DMA(4, 32, 2, 2);
+            YT_DMA_MAIN(4, 32, 2, 2);
         }
+#endif
+#undef YT_DMA_MAIN
 #undef YT_DMA
+#undef YT_DMA_X
         return 0;
     }
+#ifndef YT_DEV_X3_BIG
     if constexpr (BM <= 128) {
         if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
         else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
         else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
     }
+#endif
     return 0;
 }
 
@@ -883,8 +980,10 @@ static void launch_bf16(GemmArgs& g, hipStream_t s) {
     g.tiles_n = (int)cdiv(g.N, bt);
     g.ntiles = g.tiles_m * g.tiles_n;
     const dim3 grid(g.ntiles * g.splits);
+#ifndef YT_DEV_X3_BIG
     if (big) hipLaunchKernelGGL((gemm_dma_kernel<256, 256, true, true, 8, 32, 2, 2, true>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, true, true, 8, 32, 2, 4, true>), grid, dim3(512), 0, s, g);
+#endif
 }
 
 }  // namespace ytvln
@@ -900,7 +999,8 @@ extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, in
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
-    const int splits = std::max(plan_splits(M, N, K, epilogue), plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points
+    const int splits = std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, false, false, true).splits),
+                                plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points and the fp32x3 plan
     int64_t need = splits > 1 ? (int64_t)splits * M * N : 0;
     if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
     return need;
@@ -923,6 +1023,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     hipStream_t s = as_stream(stream);
     g.splits = 1; g.kchunk = K; g.ws = nullptr; g.sk_flags = nullptr;
+    g.x3 = (flags & YTVLN_GEMM_SPLIT_BF16X3) != 0;
     // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
     // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
     // B's k rows are clamped -- B must be [K,N]), and an M-contiguous A may have M % 4 != 0.
@@ -935,7 +1036,8 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
     g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
              !getenv("YTVLN_GEMM_GENERIC");
-    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && !transA, g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems());
+    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && !transA, g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems(),
+                          g.x3 && g.fast);
     if (plan.streamk) {
         g.tiles_m = (int)cdiv(M, 128); g.tiles_n = (int)cdiv(N, 128); g.ntiles = g.tiles_m * g.tiles_n;
         g.splits = 1; g.kchunk = g.Kloop; g.ws = workspace;
@@ -943,10 +1045,12 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         hipMemsetAsync(g.sk_flags, 0, SK_GRID * sizeof(int), s);
         static const int skg = getenv("YTVLN_GEMM_SKGRID") ? std::min(SK_GRID, std::max(8, atoi(getenv("YTVLN_GEMM_SKGRID")) / 8 * 8)) : 256;      // one workgroup per CU measured best (95.6 vs 88.5 TFLOP/s with two)
         const dim3 grid(skg), blk(512);
+#ifndef YT_DEV_X3_BIG
         if (!transA && transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, blk, 0, s, g);
         else if (!transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, blk, 0, s, g);
         else if (transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<false, false>), grid, blk, 0, s, g);
         else hipLaunchKernelGGL((gemm_streamk_kernel<false, true>), grid, blk, 0, s, g);
+#endif
         YT_LAUNCH_CHECK("gemm_f32 (stream-K)");
         return 0;
     }
@@ -959,7 +1063,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         plan.splits = 1;
         double bt = 1e30;
         for (int tile = 0; tile < 3; ++tile) {
-            const double t = plan_cost(M, N, K, tile, 1);
+            const double t = plan_cost(M, N, K, tile, 1, 0, g.x3 != 0);
             if (t < bt * 0.98) { bt = t; plan.tile = tile; }
         }
     }
@@ -1029,7 +1133,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias = bias; g.aux = aux;
     g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
-    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr;
+    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr; g.x3 = 0;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
     const int want = plan_splits_bf16(M, N, K / 2, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {

@@ -70,6 +70,7 @@ SIGNATURES = {
 
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
 GEMM_A_ZERO_PADDED = 1
+GEMM_SPLIT_BF16X3 = 2
 ABI_VERSION = 1
 
 _lib = None

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import EPI_GELU, EPI_MUL_DGELU, EPI_NONE, EPI_RELU, GEMM_A_ZERO_PADDED, call
+from ._lib import EPI_GELU, EPI_MUL_DGELU, EPI_NONE, EPI_RELU, GEMM_A_ZERO_PADDED, GEMM_SPLIT_BF16X3, call
 
 Tensor = torch.Tensor
 _ACT = {"none": EPI_NONE, None: EPI_NONE, "gelu": EPI_GELU, "relu": EPI_RELU}
@@ -102,12 +102,15 @@ _MATMUL_PRECISION = "fp32"
 
 
 def set_matmul_precision(mode: str) -> None:
-    """"fp32" (default, the reference's arithmetic) or "bf16": dense projections stage their operands in bf16 and run on
-    v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE config 5); everything else -- attention, LayerNorm, losses,
-    master weights, optimizer -- stays fp32.  Process-wide switch, read at call time."""
+    """"fp32" (default, the reference's arithmetic: v_mfma_f32_32x32x2_f32), "bf16" or "fp32x3".
+    "bf16": dense projections stage their operands in bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE
+    config 5), attention feeds bf16 operands to the matrix cores; LayerNorm, softmax, losses, master weights, optimizer stay fp32.
+    "fp32x3": dense projections keep fp32 operands and split every value exactly into three bf16 terms in registers; each product is
+    accumulated in fp32 from the six largest cross terms on the bf16 matrix instruction (YTVLN_GEMM_SPLIT_BF16X3: error per product
+    of the order of one fp32 rounding).  Attention and everything else as in "fp32".  Process-wide switch, read at call time."""
     global _MATMUL_PRECISION
-    if mode not in ("fp32", "bf16"):
-        raise ValueError(f"matmul precision must be 'fp32' or 'bf16', got {mode!r}")
+    if mode not in ("fp32", "bf16", "fp32x3"):
+        raise ValueError(f"matmul precision must be 'fp32', 'bf16' or 'fp32x3', got {mode!r}")
     _MATMUL_PRECISION = mode
 
 
@@ -163,6 +166,8 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
         call("ytvln_gemm_bf16_nt", _ptr(Ab), la, _ptr(Bb), lb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, M, N, la, epi, float(beta),
              _ptr(ws), need, _stream())
         return
+    if _MATMUL_PRECISION == "fp32x3":
+        flags = int(flags) | GEMM_SPLIT_BF16X3
     call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
          M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _stream())
 
