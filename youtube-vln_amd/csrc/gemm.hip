@@ -730,9 +730,12 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     const double need = tile == 1 ? 2.0 : tile == 2 ? 3.0 : 1.0, per_cu = std::max(1.0, blocks / 256.0);
     const double occ = per_cu < need ? need / per_cu : 1.0;
     // fused activations read / write a second matrix in the epilogue: dearer for the 256-row tiles (64-128 KB per workgroup, no overlap)
-    const double tf = tfix[tile] + ((tile >= 3 && epilogue != YTVLN_EPI_NONE) ? 10.0 : 0.0);
+    double tf = tfix[tile] + ((tile >= 3 && epilogue != YTVLN_EPI_NONE) ? 10.0 : 0.0);
+    if (x3 && tile == 4 && splits > 1) tf = 10.0;        // raw partial tiles: no fused epilogue to expose
     double t = waves * (tf + (double)(kchunk / BK) * tk[tile] * occ);
-    if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / 3.0e6;     // us: launch + bytes at ~3 TB/s
+    // us: reduce launch + workspace bytes at ~3 TB/s (fitted on the native plans; the three-term plans were fitted with 5 TB/s: their
+    // partials are consumed sooner and mostly hit the memory-side cache)
+    if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / (x3 ? 5.0e6 : 3.0e6);
     return t;
 }
 
@@ -747,7 +750,7 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
     for (int tile = 0; tile < 5; ++tile) {
         if (force_tile >= 0 && tile != force_tile) continue;
         if (tile >= 3 && (!big_ok || big < tile - 2 || M < 256)) continue;
-        const int smax = (tile == 0 && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
+        const int smax = ((tile == 0 || (tile == 4 && x3)) && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
             const double t = plan_cost(M, N, K, tile, sp, epilogue, x3);
@@ -999,8 +1002,9 @@ extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, in
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
-    const int splits = std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, false, false, true).splits),
-                                plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points and the fp32x3 plan
+    const int splits = std::max(std::max(plan_splits(M, N, K, epilogue), std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
+                                                                                      plan_gemm(M, N, K, epilogue, true, false, true).splits)),
+                                plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points and the fp32x3 plans
     int64_t need = splits > 1 ? (int64_t)splits * M * N : 0;
     if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
     return need;
@@ -1036,7 +1040,10 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
     g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
              !getenv("YTVLN_GEMM_GENERIC");
-    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && !transA, g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems(),
+    // three-term form: the 256x256 tile also takes an M-contiguous A (the split's VALU work dominates the four ds_read_b32 per fragment)
+    // and split-K: 1024x1024x16128 144 -> 186, 4480x768x3072 136 -> 171 TFLOP/s (YTVLN_X3_BIG_TA=0 restores the native rule)
+    static const int x3_big_ta = getenv("YTVLN_X3_BIG_TA") ? atoi(getenv("YTVLN_X3_BIG_TA")) : 1;
+    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && (!transA || (g.x3 && x3_big_ta)), g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems(),
                           g.x3 && g.fast);
     if (plan.streamk) {
         g.tiles_m = (int)cdiv(M, 128); g.tiles_n = (int)cdiv(N, 128); g.ntiles = g.tiles_m * g.tiles_n;
@@ -1069,7 +1076,8 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     }
     if (g.splits == 1) g.kchunk = std::max(g.kchunk, g.Kloop);
     if (g.splits > 1) {
-        launch_tile<128, 128>(g, transA, transB, s);
+        if (plan.tile == 4) launch_tile<256, 256>(g, transA, transB, s);
+        else launch_tile<128, 128>(g, transA, transB, s);
         const int64_t total = (int64_t)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
                            ldc, bias, M, N, g.splits, beta);
