@@ -607,6 +607,28 @@ def test_gemm_fp32_split_bf16x3(dev, lib, M, N, K, ta, tb, epi):
     assert not torch.equal(outs["fp32"], outs["fp32x3"]), "fp32x3 reproduced the native kernel bit for bit: the split path did not run"
 
 
+def test_gemm_fp32_split_bf16x3_dynamic_range(dev, lib):
+    """The three-term split is exact for every finite fp32 value (bf16 shares fp32's exponent range), so rows / columns scaled over
+    twenty orders of magnitude keep the fp32-level error RELATIVE to their own scale (a bf16-rounded operand would be off by 4e-3)."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 384, 256
+    sa = 10.0 ** (torch.rand(M, 1, generator=g) * 20 - 10)
+    sb = 10.0 ** (torch.rand(N, 1, generator=g) * 20 - 10)
+    A = (torch.randn(M, K, generator=g) * sa).to(dev)
+    B = (torch.randn(N, K, generator=g) * sb).to(dev)
+    C = torch.empty(M, N, device=dev)
+    ops.set_matmul_precision("fp32x3")
+    try:
+        ops._gemm(A, K, 0, B, K, 1, C, N, M, N, K)
+    finally:
+        ops.set_matmul_precision("fp32")
+    ref = A.double().cpu() @ B.double().cpu().t()
+    scale = (A.double().cpu().abs() @ B.double().cpu().abs().t())          # sum_k |a||b|: the natural error scale of a dot product
+    rel = float(((C.double().cpu() - ref).abs() / scale).max())
+    assert rel < 2e-6, rel
+
+
 def test_edge_cases_and_loud_failures(dev, lib):
     """Empty problems are no-ops; illegal arguments raise with the library's message (no silent fallback of any kind)."""
     from ytvln import ops
