@@ -719,7 +719,8 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
     // us per 32-deep k-tile at the CU-exclusive rate: native fp32 MFMA | three-bf16-term form (fitted on 16128x1024x1024: the split's
     // VALU work is shared best by the wide wave tiles -- 128x128 is VALU-bound, 256x256 matrix-bound)
-    static const double tk_f32[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tk_x3[5] = {1.61, 0.82, 0.45, 2.86, 4.94};
+    // (64x64 and 256x128 exist only for the native instruction: the three-term planner sees their native cost)
+    static const double tk_f32[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tk_x3[5] = {1.61, 0.82, 0.55, 4.16, 4.94};
     static const double tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
     const double* tk = x3 ? tk_x3 : tk_f32;
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
@@ -829,13 +830,15 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         if constexpr (BM == 256 && BN == 256) {
             YT_DMA_MAIN(8, 32, 2, 2);               // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
-            YT_DMA_MAIN(8, 32, 2, 2);               // 8 waves of 64x64, one workgroup per CU
+            YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x64, one workgroup per CU (native instruction only, like 64x64)
         } else if constexpr (BM == 128 && BN == 128) {
             if (cfg == 1 && !g.x3) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
             else if (cfg == 2 && !g.x3 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
             else YT_DMA_MAIN(8, 32, 2, 4);
-        } else {
+        } else if constexpr (BM == 128 && BN == 64) {
             YT_DMA_MAIN(4, 32, 2, 2);
+        } else {
+            YT_DMA(4, 32, 2, 2);
         }
 #endif
 #undef YT_DMA_MAIN
