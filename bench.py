@@ -11,6 +11,8 @@ exactly the body of the reference's train_epoch (utils/utils_init.py:199-239).  
 Prints ONE JSON line (rank 0).  Besides the driver contract it carries
   roofline     -- the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their HIP-event time, measured
                   live on the launch stream during the timed steps, against the 157.3 TFLOP/s fp32 matrix peak;
+  variants     -- (N = 1, default precision only; NOT the headline) the same captured step re-timed with the opt-in fp32x3 projections
+                  (fp32 operands, three exact bf16 terms per value, six bf16 MFMAs per product; DESIGN.md 5a); --no-variants skips it;
   cpu_baseline -- the CPU oracle (a port of the reference's path, oracle/vilbert_ref.py) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -58,6 +60,7 @@ def parse():
     ap.add_argument("--workload", default="cfg2_full_pretrain_bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--bs", type=int, default=None, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) fp32x3 measurement of the default run")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="auto|on: replay the step from hipGraphs (1 GPU: one graph; N GPUs: two graphs around the RCCL all-reduce), falling back to eager launches if capture fails; off: eager launches")
@@ -427,6 +430,42 @@ def main():
             print(f"{'M':>7} {'N':>6} {'K':>6} tA tB {'calls':>6} {'ms':>9} {'TF/s':>7}", file=sys.stderr)
             for (M, N, Kk, ta, tb), (c, msx, fl) in rows[:40]:
                 print(f"{M:7d} {N:6d} {Kk:6d} {ta:2d} {tb:2d} {c:6d} {msx:9.3f} {fl / msx / 1e9:7.1f}", file=sys.stderr)
+    if world == 1 and a.precision == "fp32" and use_graph and a.h2d == "off" and not a.no_variants:
+        # NOT the headline: the same captured step with the opt-in fp32x3 projections (fp32 operands, three exact bf16 terms per value,
+        # six bf16 MFMAs per product; same parity bar as the native instruction), timed after everything above.
+        try:
+            yt_ops.set_matmul_precision("fp32x3")
+            base = a.warmup + a.steps + 8
+            for i in range(2):
+                eager_step(base + i)
+            torch.cuda.synchronize()
+            g3 = torch.cuda.CUDAGraph()
+            st3 = {}
+            with torch.cuda.graph(g3):
+                st3["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
+                                                        loss_aware_heads=a.loss_aware_heads)
+            torch.cuda.synchronize()
+
+            def step3():
+                opt.prepare_replay()
+                g3.replay()
+                sched.step()
+            for _ in range(2):
+                step3()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(a.steps):
+                step3()
+            torch.cuda.synchronize()
+            e3 = time.perf_counter() - t3
+            assert np.isfinite(float(st3["loss"])), "fp32x3 variant diverged"
+            out["variants"] = {"fp32x3": {"value": round(bs * K * a.steps / e3, 3), "unit": "pairs/s", "ms_per_step": round(1000.0 * e3 / a.steps, 3),
+                                          "note": "opt-in --precision fp32x3, not the headline: fp32 operands split exactly into 3 bf16 terms in "
+                                                  "registers, 6 bf16 MFMAs per product, f32 accumulate; meets the fp32 parity bar (DESIGN.md 5a)"}}
+        except Exception as e:      # never let the extra measurement endanger the headline line
+            out["variants"] = {"fp32x3": {"error": f"{type(e).__name__}: {e}"}}
+        finally:
+            yt_ops.set_matmul_precision("fp32")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.workload)
     if rank == 0:
