@@ -42,6 +42,8 @@ TRAIN_GFLOP_PER_PAIR = 223.9   # algorithmic, T=80 R=288 full config, training =
 WORKLOADS = {
     # name: (config json, bs, K, T, frames, boxes, flags)
     "cfg2_full_pretrain_bs8": ("bert_base_6_layer_6_connect.json", 8, 7, 80, 8, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
+    # the other reading of "bs=8" -- 8 model rows (K = 1 option per item), same losses; a latency-sized launch set
+    "cfg2_k1_rows8": ("bert_base_6_layer_6_connect.json", 8, 1, 80, 8, 36, dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)),
     "cfg1_tiny_mlm_bs2": ("tiny_2_2_1.json", 2, 7, 16, 1, 8, dict(masked_language=True)),
     # BASELINE configs[3]: train.py --ranking --shuffle_visual_features, 4 beams + 2 negatives, 7 steps x 36 regions, bs=16/GPU
     # BASELINE configs[4]: bf16 MFMA path + fused AdamW, long-trajectory stress (16 frames x 36 regions), bs=32/GPU; run with --precision bf16
