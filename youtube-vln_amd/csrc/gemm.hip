@@ -9,6 +9,9 @@
 // Operands whose K dimension is contiguous in memory (x[M,K], nn.Linear weight [N,K]) are transposed on the LDS write
 // (row pitch BM+1 -> conflict-free); operands with M/N contiguous (dY^T, x^T views for the backward GEMMs) are written
 // with 16-byte stores (row pitch BM).
+// (That paragraph describes gemm_f32_kernel, the generic register-staged kernel.  The production path is gemm_dma_kernel further
+//  down: LDS-DMA operand delivery, 64x64 ... 256x256 tiles, fused epilogues, deterministic split-K; the same kernel also exists with
+//  bf16-staged operands (BF16) and in the three-bf16-term form of fp32 (X3, YTVLN_GEMM_SPLIT_BF16X3).)
 #include "common.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -822,6 +825,9 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         return 0;
 #else
         static const int cfg = getenv("YTVLN_GEMM_CFG") ? atoi(getenv("YTVLN_GEMM_CFG")) : 0;
+        // three-term 128x128 tiles run 4 waves of 64x64 (two workgroups per CU): 7.3 instead of 11 VALU ops per MFMA, +5-8 % on the
+        // unsplit shapes (16128x1024x1024 forced onto this tile: 154 -> 166 TFLOP/s); YTVLN_X3_W4=0 restores the 8-wave layout
+        static const int x3w4 = getenv("YTVLN_X3_W4") ? atoi(getenv("YTVLN_X3_W4")) : 1;
         // 128x128 tiles run 8 waves per workgroup (4 per SIMD at 2 workgroups/CU): measured 113 -> 121 TFLOP/s on
         // 16128x1024x1024 and 84 -> 105 on the split-K weight gradients versus 4 waves (barrier coupling across SIMDs).
         // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
@@ -834,6 +840,7 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         } else if constexpr (BM == 128 && BN == 128) {
             if (cfg == 1 && !g.x3) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
             else if (cfg == 2 && !g.x3 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
+            else if (g.x3 && x3w4) YT_DMA_X(4, 32, 2, 2, true);
             else YT_DMA_MAIN(8, 32, 2, 4);
         } else if constexpr (BM == 128 && BN == 64) {
             YT_DMA_MAIN(4, 32, 2, 2);
