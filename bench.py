@@ -423,6 +423,13 @@ def main():
                  "fp32x3": "ytvln::gemm_dma_kernel<X3> (6 x v_mfma_f32_32x32x16_bf16 per product; peak = bf16 dense peak / 6)"}[a.precision]
         if a.precision != "fp32":
             traffic, traffic_note = None, None
+        if a.precision == "fp32x3":
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_n_fp32x3_pmc_summary.json")))
+                traffic = pmc["kernels"]["gemm_dma"]["hbm_side_bytes_per_launch"]
+                traffic_note = "profiles/round1_n_fp32x3_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
+            except (OSError, KeyError, ValueError):
+                pass
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": traffic, "traffic_source": traffic_note, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
