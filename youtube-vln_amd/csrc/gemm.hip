@@ -530,6 +530,28 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
 }
 
+// The three-term (X3) kernels are instantiated in their own translation unit -- gemm_x3.hip includes this file with YT_GEMM_X3_TU
+// defined -- so that the two halves of the GEMM code compile in parallel.  128x128 tiles run as 4 waves of 64x64 there (two workgroups
+// per CU: 7.3 instead of 11 VALU ops per MFMA, 154 -> 166 TFLOP/s on 16128x1024x1024 forced onto that tile).
+void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s);
+
+#ifdef YT_GEMM_X3_TU
+template <int BM, int BN, int NW, int WPS>
+static void launch_x3_tile(const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
+    const dim3 gr(grid), blk(NW * 64);
+    if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
+    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
+}
+void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
+    if (bm == 256 && bn == 256) launch_x3_tile<256, 256, 8, 2>(g, transA, transB, grid, s);     // 8 waves of 64x128, one workgroup per CU
+    else if (bm == 128 && bn == 128) launch_x3_tile<128, 128, 4, 2>(g, transA, transB, grid, s);
+    else launch_x3_tile<128, 64, 4, 2>(g, transA, transB, grid, s);
+}
+}  // namespace ytvln
+#else       // ---- everything below belongs to the main translation unit -------------------------------------------------------------
+
 // Cross-XCD exchange of stream-K partial tiles without cache-wide fences (guide, section 5.7): write-through (sc1) 16-byte stores,
 // vmcnt drain, workgroup barrier, ONE relaxed agent-scope flag store; the owner polls the flag relaxed (an acquire poll would invalidate
 // its L1 on every iteration) and reads the slab with sc1 loads.
@@ -805,62 +827,45 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.ntiles = g.tiles_m * g.tiles_n;
     dim3 grid(g.ntiles * g.splits), block(256);
     if (g.fast) {
-#define YT_DMA_X(NW, KB, NS, WPS, X3V)                                                                                                 \
+#define YT_DMA(NW, KB, NS, WPS)                                                                                                        \
     do {                                                                                                                               \
         dim3 blk(NW * 64);                                                                                                             \
-        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g);        \
-        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g); \
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g); \
-        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, KB, NS, WPS, false, X3V>), grid, blk, 0, s, g);                         \
+        if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);          \
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);                           \
     } while (0)
-#define YT_DMA(NW, KB, NS, WPS) YT_DMA_X(NW, KB, NS, WPS, false)
-// the production configurations also exist in the three-bf16-term form (YTVLN_GEMM_SPLIT_BF16X3)
-#define YT_DMA_MAIN(NW, KB, NS, WPS)                  \
-    do {                                              \
-        if (g.x3) YT_DMA_X(NW, KB, NS, WPS, true);    \
-        else YT_DMA_X(NW, KB, NS, WPS, false);        \
-    } while (0)
-#ifdef YT_DEV_X3_BIG      // development builds: only the 256x256 three-term kernels are instantiated (minutes -> seconds of compile time)
-        if constexpr (BM == 256 && BN == 256) YT_DMA_X(8, 32, 2, 2, true);
-        return 0;
-#else
         static const int cfg = getenv("YTVLN_GEMM_CFG") ? atoi(getenv("YTVLN_GEMM_CFG")) : 0;
-        // three-term 128x128 tiles run 4 waves of 64x64 (two workgroups per CU): 7.3 instead of 11 VALU ops per MFMA, +5-8 % on the
-        // unsplit shapes (16128x1024x1024 forced onto this tile: 154 -> 166 TFLOP/s); YTVLN_X3_W4=0 restores the 8-wave layout
-        static const int x3w4 = getenv("YTVLN_X3_W4") ? atoi(getenv("YTVLN_X3_W4")) : 1;
+        // the tiles the three-term planner uses also exist in that form (YTVLN_GEMM_SPLIT_BF16X3): their own translation unit
+        if (g.x3 && ((BM == 256 && BN == 256) || (BM == 128 && BN == 128) || (BM == 128 && BN == 64))) {
+            launch_x3(BM, BN, g, transA, transB, grid.x, s);
+            return 0;
+        }
         // 128x128 tiles run 8 waves per workgroup (4 per SIMD at 2 workgroups/CU): measured 113 -> 121 TFLOP/s on
         // 16128x1024x1024 and 84 -> 105 on the split-K weight gradients versus 4 waves (barrier coupling across SIMDs).
         // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
         if constexpr (BM == 256 && BN == 256) {
-            YT_DMA_MAIN(8, 32, 2, 2);               // 8 waves of 64x128, one workgroup per CU
+            YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x64, one workgroup per CU (native instruction only, like 64x64)
         } else if constexpr (BM == 128 && BN == 128) {
-            if (cfg == 1 && !g.x3) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
-            else if (cfg == 2 && !g.x3 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
-            else if (g.x3 && x3w4) YT_DMA_X(4, 32, 2, 2, true);
-            else YT_DMA_MAIN(8, 32, 2, 4);
-        } else if constexpr (BM == 128 && BN == 64) {
-            YT_DMA_MAIN(4, 32, 2, 2);
+            if (cfg == 1) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
+            else if (cfg == 2 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
+            else YT_DMA(8, 32, 2, 4);
         } else {
             YT_DMA(4, 32, 2, 2);
         }
-#endif
-#undef YT_DMA_MAIN
 #undef YT_DMA
-#undef YT_DMA_X
         return 0;
     }
-#ifndef YT_DEV_X3_BIG
     if constexpr (BM <= 128) {
         if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, g);
         else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, g);
         else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, g);
     }
-#endif
     return 0;
 }
 
@@ -993,10 +998,8 @@ static void launch_bf16(GemmArgs& g, hipStream_t s) {
     g.tiles_n = (int)cdiv(g.N, bt);
     g.ntiles = g.tiles_m * g.tiles_n;
     const dim3 grid(g.ntiles * g.splits);
-#ifndef YT_DEV_X3_BIG
     if (big) hipLaunchKernelGGL((gemm_dma_kernel<256, 256, true, true, 8, 32, 2, 2, true>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, true, true, 8, 32, 2, 4, true>), grid, dim3(512), 0, s, g);
-#endif
 }
 
 }  // namespace ytvln
@@ -1062,12 +1065,10 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         hipMemsetAsync(g.sk_flags, 0, SK_GRID * sizeof(int), s);
         static const int skg = getenv("YTVLN_GEMM_SKGRID") ? std::min(SK_GRID, std::max(8, atoi(getenv("YTVLN_GEMM_SKGRID")) / 8 * 8)) : 256;      // one workgroup per CU measured best (95.6 vs 88.5 TFLOP/s with two)
         const dim3 grid(skg), blk(512);
-#ifndef YT_DEV_X3_BIG
         if (!transA && transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, blk, 0, s, g);
         else if (!transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, blk, 0, s, g);
         else if (transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<false, false>), grid, blk, 0, s, g);
         else hipLaunchKernelGGL((gemm_streamk_kernel<false, true>), grid, blk, 0, s, g);
-#endif
         YT_LAUNCH_CHECK("gemm_f32 (stream-K)");
         return 0;
     }
@@ -1169,3 +1170,4 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     YT_LAUNCH_CHECK("gemm_bf16_nt");
     return 0;
 }
+#endif  // YT_GEMM_X3_TU

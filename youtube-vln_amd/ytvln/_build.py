@@ -33,6 +33,16 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _src_mtime(src: str) -> float:
+    """mtime of a source and of the .hip files it includes (gemm_x3.hip is gemm.hip compiled with another macro set)."""
+    t = os.path.getmtime(src)
+    for line in open(src):
+        line = line.strip()
+        if line.startswith('#include "') and line.endswith('.hip"'):
+            t = max(t, os.path.getmtime(os.path.join(CSRC, line[10:-1])))
+    return t
+
+
 def _headers_mtime() -> float:
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
@@ -46,7 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(_src_mtime(src), hm):
             jobs.append((src, obj))
 
     def compile_one(job):
