@@ -56,7 +56,8 @@ enum {
 #define YTVLN_GEMM_A_ZERO_PADDED 1
 /* opt-in: every fp32 operand value is split exactly into three bf16 terms in registers and each product is accumulated in fp32
  * from the six largest cross terms on the bf16 matrix instruction (error per product ~ one fp32 rounding; LDS-DMA path only,
- * ignored by the generic kernel and by stream-K launches) */
+ * ignored by the generic kernel and by stream-K launches).  Finite inputs only: an infinite operand value yields NaN (inf - inf in the
+ * split) where the native instruction would propagate the infinity. */
 #define YTVLN_GEMM_SPLIT_BF16X3 2
 int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
 /* Introspection (host only, no GPU work): the tile shape and split count the launch planner picks for an aligned problem of this size
