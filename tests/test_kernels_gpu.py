@@ -569,7 +569,8 @@ def test_gemm_bf16_staged(dev, lib, M, N, K, ta, tb, epi):
 @pytest.mark.parametrize("M,N,K,ta,tb,epi", [
     (384, 256, 256, 0, 1, 0), (300, 200, 96, 0, 0, 0), (300, 200, 96, 1, 0, 0), (260, 132, 64, 1, 1, 0), (512, 384, 256, 0, 1, 1),
     (128, 256, 4096, 1, 0, 0), (1000, 520, 160, 0, 1, 3),
-    (3600, 3592, 128, 0, 1, 0), (4096, 1024, 512, 0, 0, 0), (3080, 1024, 96, 0, 1, 1)])      # the last three: 256-row tiles
+    (3600, 3592, 128, 0, 1, 0), (4096, 1024, 512, 0, 0, 0), (3080, 1024, 96, 0, 1, 1),      # 256-row tiles
+    (1024, 1024, 4096, 1, 0, 0), (772, 3072, 1024, 1, 0, 0)])      # weight-gradient layout (M-contiguous A) on 256x256 tiles with split-K
 def test_gemm_fp32_split_bf16x3(dev, lib, M, N, K, ta, tb, epi):
     """fp32x3 projections (YTVLN_GEMM_SPLIT_BF16X3): fp32 operands, every value split exactly into three bf16 terms in registers,
     six bf16 MFMAs per product with fp32 accumulation.  Bar: the SAME as the native fp32 MFMA path -- max error against the fp64
