@@ -63,6 +63,9 @@ int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
 /* Introspection (host only, no GPU work): the tile shape and split count the launch planner picks for an aligned problem of this size
  * (transA = 1: M-contiguous A, which excludes the 256-row tiles).  Used by tests and by tools/ to explain a measurement. */
 int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits);
+/* the same for a launch carrying YTVLN_GEMM_SPLIT_BF16X3 (its planner has its own per-tile costs; 256x256 tiles also for transA = 1 and
+ * with split-K) */
+int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits);
 int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                    float beta, float* workspace, int64_t workspace_elems, int flags, void* stream);

@@ -116,3 +116,16 @@ def test_gemm_launch_planner_host_logic():
     assert plan(1024, 1024, 16128, transA=1, epi=1)[2] == 1    # fused activations never split
     assert plan(30522, 768, 4480, transA=1)[0] == 128          # an M-contiguous A never takes the 256-row tiles
     assert lib.ytvln_gemm_plan(0, 8, 8, 0, 0, None, None, None) != 0
+
+    def plan_x3(M, N, K, transA=0, epi=0):      # the three-bf16-term form of the fp32 GEMM has its own cost table
+        tm, tn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.ytvln_gemm_plan_x3(M, N, K, transA, epi, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp)) == 0
+        return tm.value, tn.value, sp.value
+
+    assert plan_x3(16128, 1024, 1024) == (256, 256, 1)
+    tm, tn, sp = plan_x3(1024, 1024, 16128, transA=1)          # weight gradient: 16 wide tiles x 16 k-slabs = one block per CU
+    assert (tm, tn) == (256, 256) and sp >= 8
+    tm, tn, sp = plan_x3(4480, 768, 3072)                      # 54 wide tiles: split-K fills the chip (native plan: 210 tiles of 128x128)
+    assert (tm, tn) == (256, 256) and sp >= 2
+    assert plan_x3(4480, 3072, 768, epi=1)[2] == 1             # fused activations never split
+    assert plan_x3(768, 768, 4480, transA=1)[:2] != (256, 256)   # 9 wide tiles cannot fill 256 CUs even with 16 k-slabs

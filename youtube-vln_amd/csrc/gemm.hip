@@ -1014,6 +1014,15 @@ extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, in
     return 0;
 }
 
+extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
+    YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan_x3: bad argument");
+    (void)transA;       // the three-term form takes the 256-row tiles with either A layout (see ytvln_gemm_f32)
+    static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
+    const Plan p = plan_gemm(M, N, K, epilogue, true, false, true);
+    *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
+    return 0;
+}
+
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
     const int splits = std::max(std::max(plan_splits(M, N, K, epilogue), std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
                                                                                       plan_gemm(M, N, K, epilogue, true, false, true).splits)),
