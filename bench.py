@@ -480,6 +480,9 @@ def main():
                 yt_ops._gemm(Aq, 1024, 0, Bq, 1024, 1, Cq, 1024, 4096, 1024, 1024)
                 errs[mode] = float((Cq.double() - refq).abs().max() / refq.abs().max())
             yt_ops.set_matmul_precision("fp32x3")
+            if "roofline" in out:
+                out["roofline"]["trace_note"] = ("in a kernel trace of this command the headline kernel is every gemm_dma_kernel<..., false, false> "
+                                                 "instantiation; the <..., false, true> launches belong to variants.fp32x3 (--no-variants omits them)")
             out["variants"] = {"fp32x3": {"value": round(bs * K * a.steps / e3, 3), "unit": "pairs/s", "ms_per_step": round(1000.0 * e3 / a.steps, 3),
                                           "note": "opt-in --precision fp32x3, not the headline: fp32 operands split exactly into 3 bf16 terms in "
                                                   "registers, 6 bf16 MFMAs per product, f32 accumulate; meets the fp32 parity bar (DESIGN.md 5a)",
