@@ -519,6 +519,8 @@ YT_ATTN_KERNELS(attn_bwd_dkv, attn_bwd_dkv_body, __launch_bounds__(256))
 
 static int pick_waves(int T) {
     // waves per workgroup (32 rows each): least padding first, then the most waves (they share the staged tiles)
+    static const int force = getenv("YTVLN_ATTN_WAVES") ? atoi(getenv("YTVLN_ATTN_WAVES")) : 0;      // experiment knob
+    if (force >= 1 && force <= 4) return force;
     int best = 1, best_pad = 1 << 30;
     for (int nw = 4; nw >= 1; --nw) {
         const int pad = (int)cdiv(T, 32 * nw) * 32 * nw - T;
