@@ -15,6 +15,9 @@ Prints ONE JSON line (rank 0).  Besides the driver contract it carries
                   (fp32 operands, three exact bf16 terms per value, six bf16 MFMAs per product; DESIGN.md 5a); --no-variants skips it;
   cpu_baseline -- the CPU oracle (a port of the reference's path, oracle/vilbert_ref.py) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only).
+
+N > 1: `python bench.py --gpus N` starts its own N ranks (re-exec under torch.distributed.run on 127.0.0.1) unless a launcher already
+exported WORLD_SIZE; one rank per GPU, gradients summed over RCCL/xGMI through the C ABI's communicator (ytvln_rccl_*).
 """
 from __future__ import annotations
 
@@ -79,6 +82,9 @@ def parse():
                          "target; same losses and gradients, fewer FLOPs than the reference's full decode")
     ap.add_argument("--kernel-table", action="store_true", help="print per-shape GEMM timing to stderr")
     ap.add_argument("--eval-dropout-off", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="(diagnostic, not a measurement configuration) run the N > 1 code path -- DataParallel wrapper, two-graph step, RCCL "
+                         "all-reduce of the whole gradient arena through the C ABI communicator -- in a ONE-rank world on a single GPU")
     return ap.parse_args()
 
 
@@ -172,28 +178,55 @@ def cpu_baseline(workload, budget_s: float = 45.0):
                       f"after {1 if len(times) > 1 else 0} warm-up ({med:.2f} s/step)"}
 
 
+def self_launch(n: int):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks of ONE node under torch.distributed.run -- the command the
+    reference's README uses for its own multi-GPU runs (README.md:98-100, `python -m torch.distributed.launch --nproc_per_node ...`)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)                        # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.set_num_threads(effective_cores())
+    # host threads: the per-process share of the cores this cgroup may really use (N ranks on one node share them)
+    torch.set_num_threads(max(1, effective_cores() // max(1, world)))
     ndev = torch.cuda.device_count()
     dev_index = local_rank % ndev          # (ranks may share a device only in the gloo self-test below)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        # "nccl" is RCCL on ROCm.  YTVLN_DIST_BACKEND=gloo exists only to exercise the data-parallel code path with several
-        # ranks on ONE GPU (RCCL refuses duplicate devices); it is never a measurement configuration.
-        backend = os.environ.get("YTVLN_DIST_BACKEND", "nccl")
-        if backend == "nccl" and world > ndev:
-            raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev})")
-        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    from ytvln import distributed as D
+    collective = D.default_collective()
+    dp_wrap = world > 1 or a.dp_selftest
+    if dp_wrap:
+        # Data plane: the C ABI's own RCCL communicator (ytvln_rccl_*), torch.distributed = env:// rendezvous + gloo control plane.
+        # YTVLN_DP_COLLECTIVE=torch runs the exchange through torch.distributed instead ("nccl" = RCCL on ROCm).
+        # YTVLN_DIST_BACKEND=gloo with more ranks than GPUs exists only to exercise the N > 1 code path on ONE GPU (RCCL refuses
+        # duplicate devices); it is never a measurement configuration.
+        if world > ndev:
+            if os.environ.get("YTVLN_DIST_BACKEND") != "gloo":
+                raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev})")
+            collective = "torch"
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
+        D.init_distributed(backend="nccl" if (collective == "torch" and world <= ndev) else "gloo", force=True)
 
     from ytvln import ops as yt_ops
     from ytvln import synth, utils_init
@@ -220,11 +253,19 @@ def main():
     batch = synth.to_torch(synth.make_batch(bs=bs, K=K, T=T, frames=frames, boxes=boxes, seed=1234 + rank,
                                             finetune_heading=not args.pretrain), dev)
     runner = model
-    if world > 1:
-        runner = DataParallel(model, broadcast=True)
+    if dp_wrap:
+        runner = DataParallel(model, broadcast=True, collective=collective, always_exchange=a.dp_selftest)
     opt, sched, _, _ = get_optimization(args, model, a.steps + a.warmup + 1, None)
-    if world > 1:
+    if dp_wrap:
         runner.attach(opt)
+
+    def control_reduce(x: float, op) -> float:
+        """max / min of a host scalar over ranks on the control plane (CPU tensor: gloo; device tensor: nccl)."""
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
     timer = GemmTimer()
     if not a.no_kernel_timing:
@@ -256,7 +297,7 @@ def main():
             for i in range(2):                                 # eager steps: build the optimizer arenas, warm the allocator
                 eager_step(i)
             torch.cuda.synchronize()
-            if world == 1:
+            if not dp_wrap:
                 graph = torch.cuda.CUDAGraph()
                 static = {}
                 with torch.cuda.graph(graph):
@@ -279,14 +320,12 @@ def main():
         except Exception as e:
             print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
             ok = False
-        if world > 1:
-            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item() > 0.5)
+        ok = control_reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
         if ok:
             step = graph_step
-            execution = "hipGraph replay of the captured step" if world == 1 else \
-                "two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them"
+            execution = "hipGraph replay of the captured step" if not dp_wrap else \
+                (f"two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them "
+                 f"[{gs.mode}; exchange: {'ytvln_rccl_* C ABI' if runner.comm is not None else 'torch.distributed ' + dist.get_backend()}]")
         else:
             torch.cuda.synchronize()
             opt.zero_grad()
@@ -362,10 +401,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.on = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)
     final_loss = float(loss)
     assert np.isfinite(final_loss), "training diverged"
     if infer:
@@ -391,7 +427,8 @@ def main():
         "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate / activations / master weights",
                   "fp32x3": "f32 operands split exactly into 3 bf16 terms in registers, 6 bf16 MFMAs per product, f32 accumulate (projections); "
                             "f32 everywhere else"}[a.precision], "data": "synthetic",
-        "config": {"workload": a.workload, **({"dist_backend": os.environ["YTVLN_DIST_BACKEND"]} if "YTVLN_DIST_BACKEND" in os.environ else {}), "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
+        "config": {"workload": a.workload, **({"gradient_exchange": ("ytvln_rccl_* (C ABI, " + os.path.basename(runner.comm.library) + ")") if runner.comm is not None
+                                                  else "torch.distributed " + dist.get_backend(), "dp_selftest": bool(a.dp_selftest)} if dp_wrap else {}), "model_config": cfgname, "params": n_params, "items_per_gpu": bs, "options_per_item": K,
                    "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
                    "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
                    "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}",
@@ -439,7 +476,7 @@ def main():
             print(f"{'M':>7} {'N':>6} {'K':>6} tA tB {'calls':>6} {'ms':>9} {'TF/s':>7}", file=sys.stderr)
             for (M, N, Kk, ta, tb), (c, msx, fl) in rows[:40]:
                 print(f"{M:7d} {N:6d} {Kk:6d} {ta:2d} {tb:2d} {c:6d} {msx:9.3f} {fl / msx / 1e9:7.1f}", file=sys.stderr)
-    if world == 1 and a.precision == "fp32" and use_graph and a.h2d == "off" and not a.no_variants:
+    if world == 1 and not dp_wrap and a.precision == "fp32" and use_graph and a.h2d == "off" and not a.no_variants:
         # NOT the headline: the same captured step with the opt-in fp32x3 projections (fp32 operands, three exact bf16 terms per value,
         # six bf16 MFMAs per product; same parity bar as the native instruction), timed after everything above.
         try:
@@ -492,12 +529,14 @@ def main():
             out["variants"] = {"fp32x3": {"error": f"{type(e).__name__}: {e}"}}
         finally:
             yt_ops.set_matmul_precision("fp32")
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not dp_wrap and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.workload)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    if dp_wrap:
+        runner.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

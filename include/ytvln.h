@@ -249,6 +249,33 @@ int ytvln_bce_bwd_f32(const float* x, const float* t, const float* pos_weight, c
 int ytvln_adamw_f32(float* p, const float* g, float* m, float* v, const void* chunks, int nchunks, const float* hyper,
                     float grad_scale, void* stream);
 
+/* ---- data-parallel gradient exchange: RCCL over xGMI ------------------------------------------------------------------------
+ * Replaces DistributedDataParallel over NCCL (utils/distributed.py:63-104: init_process_group("nccl") + DDP's bucketed all-reduce).
+ * librccl is resolved with dlopen at run time (no link dependency): an explicit path, else a librccl already mapped into the
+ * process (PyTorch's own copy -- same HIP runtime, so streams and device pointers interoperate), else the loader's default.
+ * A communicator is an opaque handle owned by the caller (the one piece of state that outlives a call); collectives are
+ * asynchronous on the stream they are given and operate IN PLACE on device memory; nothing here synchronises or allocates
+ * device memory.  The 128-byte unique id is created on rank 0 and carried to the other ranks by the host (env:// store). */
+enum { YTVLN_DT_F32 = 0, YTVLN_DT_F64 = 1, YTVLN_DT_BF16 = 2, YTVLN_DT_I64 = 3, YTVLN_DT_U8 = 4 };
+enum { YTVLN_RED_SUM = 0, YTVLN_RED_MAX = 1, YTVLN_RED_MIN = 2 };
+#define YTVLN_RCCL_UNIQUE_ID_BYTES 128
+int ytvln_rccl_load(const char* path);                 /* path may be NULL / "" (see the resolution order above)            */
+const char* ytvln_rccl_library_path(void);            /* file the nccl* symbols were bound from ("" before a load)           */
+int ytvln_rccl_version(int* version);                  /* NCCL_VERSION_CODE of the loaded library                              */
+int ytvln_rccl_unique_id(void* id_out, int64_t bytes); /* ncclGetUniqueId; bytes must be YTVLN_RCCL_UNIQUE_ID_BYTES           */
+/* ncclCommInitRank (collective over all `world` ranks; blocks until they all arrive).  device >= 0: hipSetDevice first. */
+int ytvln_rccl_init(void** comm_out, const void* id, int64_t id_bytes, int rank, int world, int device);
+/* in-place all-reduce of `count` elements; dtype / op from the enums above */
+int ytvln_rccl_allreduce(void* comm, void* buf, int64_t count, int dtype, int op, void* stream);
+/* SUM all-reduce of `nslices` contiguous slices base[offsets[i] : offsets[i]+counts[i]] (HOST arrays) of one flat fp32 gradient
+ * arena as ONE RCCL group: the buckets of an optimizer step without a host round trip between them. */
+int ytvln_rccl_allreduce_slices_f32(void* comm, float* base, const int64_t* offsets, const int64_t* counts, int nslices,
+                                    void* stream);
+/* in-place byte broadcast from `root` (DDP's rank-0 weight broadcast at wrap time) */
+int ytvln_rccl_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
+int ytvln_rccl_async_error(void* comm);                /* 0 = healthy; negative + ytvln_last_error() otherwise                 */
+int ytvln_rccl_destroy(void* comm);                    /* ncclCommDestroy; NULL is a no-op                                     */
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,95 @@ def test_rank_helpers_read_the_environment(monkeypatch):
     assert (D.get_rank(), D.get_world_size(), D.get_local_rank()) == (0, 1, -1)
     monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("LOCAL_RANK", "3")
     assert (D.get_rank(), D.get_world_size(), D.get_local_rank()) == (3, 8, 3)
+
+
+def accum_worker(rank, world, port, q):
+    """Two backward passes per optimizer step: the second one must not land in already-exchanged buckets unnoticed."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ytvln import distributed as D
+    D.init_distributed(backend="gloo")
+    torch.manual_seed(5)
+    net = Net()
+    dp = D.DataParallel(net, bucket_bytes=256)
+    opt = ArenaSGD(net.parameters(), lr=0.1)
+    dp.attach(opt)
+    g = torch.Generator().manual_seed(11 + rank)
+    xs = [torch.randn(5, 6, generator=g) for _ in range(6)]
+    dp(xs[0]).pow(2).mean().backward(); opt.step(); opt.zero_grad()          # step 0 builds arena + reducer
+    # (a) the documented way: all but the last backward under no_sync()
+    with dp.no_sync():
+        dp(xs[1]).pow(2).mean().backward()
+    dp(xs[2]).pow(2).mean().backward()
+    opt.step(); opt.zero_grad()
+    chk = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    ok_sync = torch.equal(both[0], both[1])
+    # (b) forgetting it: buckets get exchanged during the first backward; the second backward's gradients arrive late -> loud error
+    dp(xs[3]).pow(2).mean().backward()
+    dp(xs[4]).pow(2).mean().backward()
+    raised = False
+    try:
+        opt.step()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    q.put((rank, ok_sync, raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_contract_no_sync_or_loud_error():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _, ok_sync, raised in res:
+        assert ok_sync, "replicas diverged under no_sync() accumulation"
+        assert raised, "a late gradient in an already-exchanged bucket must raise"
+
+
+def test_rccl_binding_resolves_pytorchs_librccl_without_a_gpu():
+    """Host-only entry points of the RCCL binding: dlopen picks the librccl PyTorch already mapped; a unique id can be drawn."""
+    import ctypes
+    from ytvln import _lib
+    from ytvln.distributed import RcclCommunicator, default_collective
+    lib = _lib.load()
+    _lib.call("ytvln_rccl_load", None)
+    path = lib.ytvln_rccl_library_path().decode()
+    assert os.path.realpath(path) == os.path.realpath(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    v = ctypes.c_int()
+    _lib.call("ytvln_rccl_version", ctypes.byref(v))
+    assert v.value >= 21000
+    uid = RcclCommunicator.new_unique_id()
+    assert len(uid) == _lib.RCCL_UNIQUE_ID_BYTES
+    with pytest.raises(RuntimeError, match="128"):
+        _lib.call("ytvln_rccl_unique_id", ctypes.create_string_buffer(64), 64)
+    with pytest.raises(RuntimeError, match="no communicator"):
+        _lib.call("ytvln_rccl_allreduce", None, None, 0, 0, 0, None)
+    assert lib.ytvln_rccl_destroy(None) == 0
+    assert default_collective() == ("rccl" if torch.cuda.is_available() else "torch")
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-execs under torch.distributed.run on 127.0.0.1 (README.md:98-100 counterpart)."""
+    import importlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(bench.os, "execv", lambda exe, argv: seen.update(exe=exe, argv=argv) or (_ for _ in ()).throw(SystemExit(0)))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    argv = seen["argv"]
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    assert argv[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and argv[-7].endswith("bench.py")

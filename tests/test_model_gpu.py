@@ -22,7 +22,7 @@ def build_lily(dev, cfgname, args, seed, dropout=0.0, **over):
     from ytvln import synth
     from ytvln.lily import Lily
     from ytvln.vilbert import BertConfig
-    cfg = BertConfig(**cfg_dict(cfgname, **ZERO_DROP, **over))
+    cfg = BertConfig(**cfg_dict(cfgname, **{**ZERO_DROP, **over}))
     cfg.args = args
     model = Lily(cfg, dropout_prob=dropout)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -284,6 +284,90 @@ def test_training_mode_dropout_runs_and_is_reproducible(dev, lib):
     assert abs(float(total_eval) - res[0][0]) > 1e-6
 
 
+def test_dropout_stream_follows_torch_seed_and_survives_a_checkpoint(dev, lib, tmp_path):
+    """the mask stream is keyed by torch's seed (the reference's set_seed -> torch.manual_seed(seed + local_rank),
+    utils/misc.py:37-45), different seeds draw different masks, and (seed, counter) travel through save_model / --resume so a resumed
+    run continues the stream instead of replaying it from 0."""
+    from ytvln import ops, synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0), dev)
+
+    def run(seed, steps, resume_from=None, save_to=None):
+        ops.DropoutState.manual_seed(None)                 # default behaviour: follow torch.initial_seed()
+        torch.manual_seed(seed)
+        a = args
+        if resume_from is not None:
+            a = args_ns(**{**vars(args), "resume": True, "from_pretrained": resume_from})
+        model, _ = build_lily(dev, "micro.json", a, seed=11, **{k: 0.1 for k in ZERO_DROP})
+        model.train()
+        opt, sched, _, _ = get_optimization(a, model, 10, None)
+        losses = []
+        first = 2 if resume_from is not None else 0
+        for i in range(first, first + steps):
+            loss, _ = U.train_step(model, opt, sched, batch, a, i, all_options=True)
+            losses.append(float(loss))
+        if save_to is not None:
+            U.save_model(str(tmp_path), save_to, None, model, opt, sched, epoch=0)
+        return losses
+
+    a4 = run(5, 4)
+    assert run(5, 4) == a4                                   # same seed: same masks
+    assert run(6, 4)[0] != a4[0]                             # another seed: other masks already in the first step
+    run(5, 2, save_to="rng")
+    st = torch.load(U.get_model_path(str(tmp_path), "rng"), map_location="cpu")["ytvln_rng_state"]
+    (seed, counter), = st.values()
+    assert seed == 5 and counter == 2
+    resumed = run(999, 2, resume_from=U.get_model_path(str(tmp_path), "rng"))     # torch seed differs: the checkpoint's stream wins
+    assert np.allclose(resumed, a4[2:], rtol=0, atol=2e-6), (resumed, a4)
+    ops.DropoutState.manual_seed(None)
+
+
+def test_optimizer_load_state_dict_after_the_arena_exists(dev, lib):
+    """load_state_dict() on an optimizer that already stepped must make the kernel use the LOADED moments and
+    state_dict() must keep returning live tensors."""
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0), dev)
+
+    def fresh():
+        m, _ = build_lily(dev, "micro.json", args, seed=11)
+        m.train()
+        return m
+
+    # run A: 3 steps straight.  Snapshot after step 2.
+    mA = fresh(); oA, sA, _, _ = get_optimization(args, mA, 10, None)
+    for i in range(2):
+        U.train_step(mA, oA, sA, batch, args, i, all_options=True)
+    snap_model = {k: v.detach().clone() for k, v in mA.state_dict().items()}
+    snap_opt = oA.state_dict()
+    for st in snap_opt["state"].values():
+        for k, v in list(st.items()):
+            if torch.is_tensor(v):
+                st[k] = v.detach().clone()
+    snap_sched = sA.state_dict()
+    U.train_step(mA, oA, sA, batch, args, 2, all_options=True)
+    # run B: an optimizer that has ALREADY built its arenas on other values, then loads the snapshot
+    mB = fresh(); oB, sB, _, _ = get_optimization(args, mB, 10, None)
+    for i in range(4):
+        U.train_step(mB, oB, sB, batch, args, i, all_options=True)
+    mB.load_state_dict(snap_model); oB.load_state_dict(snap_opt); sB.load_state_dict(snap_sched)
+    U.train_step(mB, oB, sB, batch, args, 2, all_options=True)
+    a = torch.cat([p.detach().reshape(-1) for p in mA.parameters()])
+    b = torch.cat([p.detach().reshape(-1) for p in mB.parameters()])
+    assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+    sdA, sdB = oA.state_dict()["state"], oB.state_dict()["state"]
+    for k in sdA:
+        assert sdA[k]["step"] == sdB[k]["step"] == 3
+        assert float((sdA[k]["exp_avg"] - sdB[k]["exp_avg"]).abs().max()) < 1e-6
+        assert float((sdA[k]["exp_avg_sq"] - sdB[k]["exp_avg_sq"]).abs().max()) < 1e-8
+
+
 def test_graph_replay_equals_eager(dev, lib):
     """A training step captured once into a hipGraph and replayed must produce the same parameters as eager launches."""
     from ytvln import synth
@@ -349,7 +433,7 @@ def test_save_resume_and_eval_loops(dev, lib, tmp_path):
         U.train_step(m1, o1, s1, batch, args, i, all_options=True)
     U.save_model(str(tmp_path), "ckpt", None, m1, o1, s1, epoch=7)
     ck = torch.load(U.get_model_path(str(tmp_path), "ckpt"), map_location="cpu")
-    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "epoch"}
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "epoch", "ytvln_rng_state"}
     st = next(iter(ck["optimizer_state_dict"]["state"].values()))
     assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and st["step"] == 2
     m2 = fresh()

@@ -1,0 +1,202 @@
+"""GPU: the RCCL data plane of the data-parallel path on the ONE device of the test box.
+
+RCCL refuses two ranks on one device, but a one-rank communicator is legal (`ncclCommInitRank(nranks=1)`): every collective
+really goes through librccl (kernel launch on the given stream, graph capture, group calls) and is the identity on the data,
+so a data-parallel run must equal the plain single-process run BIT FOR BIT.  Covered here:
+  * the `ytvln_rccl_*` C ABI itself (load / version / unique id / init / all-reduce / grouped slices / broadcast / destroy);
+  * `DataParallel` + bucket hooks on a comm stream, eager; `GraphedTrainStep` in both modes (exchange between two graphs; exchange
+    captured INTO the graph) -- over the C ABI communicator;
+  * the same wrapper over torch.distributed's "nccl" (= RCCL) backend with its watchdog thread alive during capture;
+  * `bench.py --gpus N` starting its own ranks (2 ranks share the GPU over gloo; utils/distributed.py:63-104, README.md:98-100).
+Each case runs in a spawned process (process-group and communicator state never leak into the other GPU tests)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from helpers import ZERO_DROP, args_ns, cfg_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build(dev):
+    from ytvln import synth
+    from ytvln.lily import Lily
+    from ytvln.vilbert import BertConfig
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    cfg = BertConfig(**cfg_dict("micro.json", **ZERO_DROP))
+    cfg.args = args
+    model = Lily(cfg, dropout_prob=0.0)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(shapes, 3).items()})
+    return model.to(dev).train(), args
+
+
+def _batch(dev, seed=40):
+    from ytvln import synth
+    return synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=seed, ignore_rank_frac=0.0), dev)
+
+
+def _flat(model):
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+
+
+def _plain_run(dev, steps=3):
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    model, args = _build(dev)
+    args.learning_rate = 1e-3
+    opt, sched, _, _ = get_optimization(args, model, 10, None)
+    batch = _batch(dev)
+    for step in range(steps):
+        U.train_step(model, opt, sched, batch, args, step, all_options=True)
+    torch.cuda.synchronize()
+    return _flat(model)
+
+
+def _worker(case, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.path.insert(0, os.path.join(ROOT, "youtube-vln_amd"))
+        import torch.distributed as dist
+        from ytvln import distributed as D, utils_init as U
+        from ytvln.vilbert_init import get_optimization
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        collective, mode = case.split(":")
+        D.init_distributed(backend="nccl" if collective == "torch" else "gloo", force=True)
+        assert dist.get_world_size() == 1 and dist.get_backend() == ("nccl" if collective == "torch" else "gloo")
+        model, args = _build(dev)
+        args.learning_rate = 1e-3
+        dp = D.DataParallel(model, bucket_bytes=64 << 10, collective=collective, always_exchange=True)
+        assert (dp.comm is not None) == (collective == "rccl")
+        info = {}
+        if dp.comm is not None:
+            info["library"] = dp.comm.library
+        opt, sched, _, _ = get_optimization(args, model, 10, None)
+        dp.attach(opt)
+        batch = _batch(dev)
+        if mode == "eager":
+            for step in range(3):
+                U.train_step(dp, opt, sched, batch, args, step, all_options=True)
+            assert dp._reducer is not None and len(dp._reducer.buckets) > 1
+            assert dp._reducer.collectives == 3 * len(dp._reducer.buckets)      # every bucket, every step
+            info["collectives"] = dp._reducer.collectives
+        else:
+            U.train_step(dp, opt, sched, batch, args, 0, all_options=True)
+            gs = D.GraphedTrainStep(dp, opt, lambda: U.train_step(dp, opt, None, batch, args, 0, all_options=True, optimizer_step=False)[0],
+                                    bucket_bytes=64 << 10, mode=mode)
+            assert gs.exchange and len(gs._slices) > 1
+            for step in range(2):
+                loss = gs.step(sched)
+            assert torch.isfinite(loss).item()
+        torch.cuda.synchronize()
+        if dp.comm is not None:
+            dp.comm.check_async_error()
+        got = _flat(model)
+        dp.close()
+        dist.destroy_process_group()
+        q.put(("ok", got, info))
+    except Exception as e:      # surface the failure in the parent instead of a bare exit code
+        import traceback
+        q.put(("error", traceback.format_exc(), {}))
+        raise e
+
+
+@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "torch:eager", "torch:split"])
+def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(case, _free_port(), q))
+    p.start()
+    status, got, info = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", got
+    assert p.exitcode == 0
+    ref = _plain_run(dev)
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())     # identity exchange, grad_scale 1: bit-identical
+    if case.startswith("rccl"):
+        assert "rccl" in os.path.basename(info["library"])
+
+
+def test_rccl_c_abi_collectives(dev, lib):
+    """The binding itself: a one-rank communicator, every entry point, results checked on the device."""
+    import ctypes
+    from ytvln import _lib
+    from ytvln.distributed import RcclCommunicator
+    v = ctypes.c_int()
+    _lib.call("ytvln_rccl_version", ctypes.byref(v))
+    assert v.value >= 21000, v.value
+    path = lib.ytvln_rccl_library_path().decode()
+    # the copy already mapped by PyTorch is the one that must be bound (same HIP runtime as torch's streams)
+    assert os.path.realpath(path) == os.path.realpath(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")), path
+    uid = RcclCommunicator.new_unique_id()
+    assert len(uid) == 128 and uid != RcclCommunicator.new_unique_id()
+    comm = RcclCommunicator(0, 1, dev, uid)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(1 << 20, generator=g).to(dev)
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce(x, "sum", stream=side)                      # on a non-default stream
+    torch.cuda.current_stream().wait_stream(side)
+    comm.all_reduce(x, "max")
+    comm.all_reduce_slices(x, [(0, 1000), (1000, 70000), (70000, x.numel())])
+    comm.broadcast(x, root=0)
+    i = torch.arange(17, device=dev)
+    comm.all_reduce(i, "sum")
+    d = torch.full((5,), 1.5, dtype=torch.float64, device=dev)
+    comm.all_reduce(d, "min")
+    torch.cuda.synchronize()
+    comm.check_async_error()
+    assert torch.equal(x, ref) and torch.equal(i, torch.arange(17, device=dev)) and float(d.sum()) == 7.5
+    with pytest.raises(RuntimeError, match="contiguous"):
+        comm.all_reduce(x.view(1024, 1024).t())
+    with pytest.raises(RuntimeError, match="lives on"):
+        comm.all_reduce(torch.zeros(4))
+    with pytest.raises(RuntimeError, match="ytvln_rccl_init failed"):
+        RcclCommunicator(3, 2, dev, uid)                        # rank outside the world: rejected before RCCL is touched
+    comm.close()
+    comm.close()                                                # idempotent
+
+
+def _run_bench(extra, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg1_tiny_mlm_bs2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-variants", *extra], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks(dev, lib):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: re-execs under torch.distributed.run, rank 0 prints ONE line.
+    (2 ranks on the single test GPU need the gloo exchange; on an N-GPU node the same command runs the RCCL communicator.)"""
+    out = _run_bench(["--gpus", "2"], {"YTVLN_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_pairs"] == 2 * out["config"]["pairs_per_gpu"]
+    assert np.isfinite(out["final_loss"]) and out["value"] > 0
+    assert "two hipGraphs" in out["config"]["execution"] or "eager" in out["config"]["execution"]
+
+
+def test_bench_dp_path_over_the_c_abi_communicator(dev, lib):
+    """The N > 1 code path of bench.py (DataParallel, two-graph step, arena all-reduce through ytvln_rccl_*) in a one-rank world."""
+    out = _run_bench(["--gpus", "1", "--dp-selftest"], {})
+    assert out["n_gpus"] == 1 and out["config"]["dp_selftest"] is True
+    assert out["config"]["gradient_exchange"].startswith("ytvln_rccl_")
+    assert "two hipGraphs" in out["config"]["execution"], out["config"]["execution"]
+    assert np.isfinite(out["final_loss"])

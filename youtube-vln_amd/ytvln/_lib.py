@@ -67,7 +67,22 @@ SIGNATURES = {
     "ytvln_bce_fwd_f32": [P, P, P, P, I32, P],
     "ytvln_bce_bwd_f32": [P, P, P, P, P, I32, P],
     "ytvln_adamw_f32": [P, P, P, P, P, I32, P, F32, P],
+    # RCCL binding (csrc/rccl.hip): host calls, the communicator is an opaque handle
+    "ytvln_rccl_load": [P],
+    "ytvln_rccl_library_path": [],
+    "ytvln_rccl_version": [P],
+    "ytvln_rccl_unique_id": [P, I64],
+    "ytvln_rccl_init": [P, P, I64, I32, I32, I32],
+    "ytvln_rccl_allreduce": [P, P, I64, I32, I32, P],
+    "ytvln_rccl_allreduce_slices_f32": [P, P, P, P, I32, P],
+    "ytvln_rccl_broadcast": [P, P, I64, I32, P],
+    "ytvln_rccl_async_error": [P],
+    "ytvln_rccl_destroy": [P],
 }
+RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p}
+DT_F32, DT_F64, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3, 4
+RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
+RCCL_UNIQUE_ID_BYTES = 128
 
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
 GEMM_A_ZERO_PADDED = 1
@@ -100,7 +115,7 @@ def load():
         except AttributeError as e:
             raise YtvlnLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = I64 if name == "ytvln_gemm_workspace_elems" else I32
+        fn.restype = RESTYPES.get(name, I32)
     if lib.ytvln_version() != ABI_VERSION:
         raise YtvlnLibraryError(f"ABI mismatch: library {lib.ytvln_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -1,8 +1,11 @@
 """Data-parallel training over RCCL/xGMI: one process per GPU, flat-bucket gradient all-reduce overlapped with backward.
 
 Counterpart of the reference's `utils/distributed.py:63-153` (`init_distributed`, `set_cuda`, `wrap_distributed_model` =
-`DistributedDataParallel(find_unused_parameters=True)`).  `torch.distributed`'s "nccl" backend IS RCCL on ROCm; the
-design choices here are for MI355X's point-to-point xGMI fabric rather than a translation of DDP's defaults:
+`DistributedDataParallel(find_unused_parameters=True)`).  The gradient exchange goes through the C ABI's own RCCL binding
+(`ytvln_rccl_*`, csrc/rccl.hip; `RcclCommunicator` below): `torch.distributed` only supplies the env:// rendezvous that carries the
+128-byte RCCL unique id and the host-side control plane (gloo).  `collective="torch"` keeps `torch.distributed.all_reduce` as the
+exchange (its "nccl" backend is RCCL too) -- the path the CPU tests drive over gloo.  The design choices are for MI355X's
+point-to-point xGMI fabric rather than a translation of DDP's defaults:
 
   * gradients already live in ONE flat fp32 arena (ytvln.optimization.AdamW), so a bucket is a contiguous slice of it --
     no flatten/unflatten copies, and few LARGE collectives (default 256 MiB buckets; DDP's 25 MB buckets would put ~40
@@ -14,12 +17,16 @@ design choices here are for MI355X's point-to-point xGMI fabric rather than a tr
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 from torch import nn
+
+from . import _lib
 
 
 def get_rank(default: int = 0) -> int:
@@ -42,19 +49,127 @@ def get_local_rank(args=None) -> int:
     return getattr(args, "local_rank", -1) if args is not None else -1
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int]:
-    """env:// rendezvous (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE), like utils/distributed.py:63-90."""
+def default_collective() -> str:
+    """"rccl": the C ABI's own RCCL communicator (default on a HIP device); "torch": torch.distributed.all_reduce."""
+    c = os.environ.get("YTVLN_DP_COLLECTIVE", "rccl" if torch.cuda.is_available() else "torch")
+    if c not in ("rccl", "torch"):
+        raise ValueError(f"YTVLN_DP_COLLECTIVE={c!r}: expected 'rccl' or 'torch'")
+    return c
+
+
+def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int]:
+    """env:// rendezvous (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE), like utils/distributed.py:63-90.
+
+    The process group is the CONTROL plane (unique-id exchange, barriers, logged metrics): gloo unless the gradient exchange itself is
+    asked to run through torch.distributed (`YTVLN_DP_COLLECTIVE=torch`), in which case it is "nccl" (= RCCL) on a HIP device.
+    `force=True` also initialises a one-rank group (tests exercise the RCCL path on a single GPU that way)."""
     world = get_world_size()
-    if world <= 1:
+    if world <= 1 and not force:
         return 0, 1
     if not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the only mode this driver supports)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, init_method="env://", rank=get_rank(), world_size=world)
+            backend = os.environ.get("YTVLN_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() and default_collective() == "torch" else "gloo")
+        if backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")         # one node: never depend on the container hostname resolving
+        dist.init_process_group(backend=backend, init_method="env://", rank=get_rank(), world_size=max(world, 1))
     return dist.get_rank(), dist.get_world_size()
+
+
+_TORCH_DT = {torch.float32: _lib.DT_F32, torch.float64: _lib.DT_F64, torch.bfloat16: _lib.DT_BF16, torch.int64: _lib.DT_I64,
+             torch.uint8: _lib.DT_U8}
+_RED = {"sum": _lib.RED_SUM, "max": _lib.RED_MAX, "min": _lib.RED_MIN}
+
+
+class RcclCommunicator:
+    """One RCCL communicator created through the C ABI (`ytvln_rccl_init`): the data plane of the data-parallel path.
+
+    Every collective is enqueued on the stream it is given (default: torch's current stream) and works in place on device memory.
+    No watchdog thread, no hidden stream: ordering against the compute kernels is whatever the caller's streams / events say, which is
+    what lets the calls sit between (or inside) hipGraphs."""
+
+    def __init__(self, rank: int, world: int, device: torch.device, unique_id: bytes):
+        if len(unique_id) != _lib.RCCL_UNIQUE_ID_BYTES:
+            raise ValueError("RCCL unique id must be 128 bytes")
+        _lib.load()
+        torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        # bind to the librccl PyTorch already mapped (same HIP runtime as our streams); fall back to its file, then the loader default
+        try:
+            _lib.call("ytvln_rccl_load", None)
+        except RuntimeError:
+            _lib.call("ytvln_rccl_load", torch_rccl.encode() if os.path.exists(torch_rccl) else None)
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        handle = ctypes.c_void_p()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.call("ytvln_rccl_init", ctypes.byref(handle), unique_id, len(unique_id), rank, world, index)
+        self._handle = handle
+        self.library = _lib.load().ytvln_rccl_library_path().decode()
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(_lib.RCCL_UNIQUE_ID_BYTES)
+        _lib.call("ytvln_rccl_unique_id", buf, _lib.RCCL_UNIQUE_ID_BYTES)
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, device, group=None) -> "RcclCommunicator":
+        """Rank 0 draws the unique id; the (already initialised) torch.distributed group carries it to the others."""
+        if dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [cls.new_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        else:
+            rank, world, box = 0, 1, [cls.new_unique_id()]
+        return cls(rank, world, device, box[0])
+
+    def _check(self, t: torch.Tensor):
+        if not t.is_cuda or t.device != self.device:
+            raise RuntimeError(f"RcclCommunicator on {self.device}: tensor lives on {t.device}")
+        if not t.is_contiguous():
+            raise RuntimeError("RCCL collectives work in place on contiguous memory")
+
+    @staticmethod
+    def _stream(stream):
+        return (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum", stream=None) -> torch.Tensor:
+        self._check(t)
+        _lib.call("ytvln_rccl_allreduce", self._handle, t.data_ptr(), t.numel(), _TORCH_DT[t.dtype], _RED[op], self._stream(stream))
+        return t
+
+    def all_reduce_slices(self, flat: torch.Tensor, slices: Sequence[Tuple[int, int]], stream=None) -> None:
+        """SUM over ranks of flat[lo:hi] for every (lo, hi), issued as one RCCL group."""
+        self._check(flat)
+        if flat.dtype != torch.float32:
+            raise RuntimeError("gradient arenas are fp32")
+        n = len(slices)
+        offs = (ctypes.c_int64 * n)(*[lo for lo, _ in slices])
+        cnts = (ctypes.c_int64 * n)(*[hi - lo for lo, hi in slices])
+        _lib.call("ytvln_rccl_allreduce_slices_f32", self._handle, flat.data_ptr(), offs, cnts, n, self._stream(stream))
+
+    def broadcast(self, t: torch.Tensor, root: int = 0, stream=None) -> torch.Tensor:
+        self._check(t)
+        _lib.call("ytvln_rccl_broadcast", self._handle, t.data_ptr(), t.numel() * t.element_size(), root, self._stream(stream))
+        return t
+
+    def check_async_error(self):
+        _lib.call("ytvln_rccl_async_error", self._handle)
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            torch.cuda.synchronize(self.device)
+            _lib.call("ytvln_rccl_destroy", self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):      # best effort; close() explicitly before the process group goes away
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def set_cuda(args=None):
@@ -72,14 +187,26 @@ def set_cuda(args=None):
 class GradBucketReducer:
     """All-reduces contiguous slices ("buckets") of a flat gradient tensor as they become ready during backward.
 
-    layout: [(param, offset, numel)] in arena order.  Device-agnostic (tested on CPU with gloo, world_size 2)."""
+    layout: [(param, offset, numel)] in arena order.  `comm` = an RcclCommunicator: a bucket is reduced on a dedicated HIP stream
+    behind an event recorded where its last gradient landed, and `finish()` makes the consumer's stream wait on the bucket events
+    (no host synchronisation).  `comm=None`: torch.distributed.all_reduce(async_op=True) -- device-agnostic, tested on CPU with
+    gloo at world_size 2.  `always` runs the collectives even in a one-rank world (single-GPU tests of the RCCL path).
+
+    Contract (DDP reduces on every backward; this reducer exchanges a bucket ONCE per optimizer step): with several backward
+    passes per step, all but the last must run with the exchange disabled (`DataParallel.no_sync()`, which
+    `utils_init.train_step` applies for gradient accumulation).  A gradient arriving for a bucket that was already exchanged
+    raises instead of silently leaving an un-reduced contribution in it."""
 
     def __init__(self, flat: torch.Tensor, layout: Sequence[Tuple[torch.nn.Parameter, int, int]], bucket_bytes: int = 256 << 20,
-                 group=None, overlap: bool = True, enabled_fn: Optional[Callable[[], bool]] = None):
-        self.flat, self.group, self.overlap = flat, group, overlap
+                 group=None, overlap: bool = True, enabled_fn: Optional[Callable[[], bool]] = None,
+                 comm: Optional[RcclCommunicator] = None, always: bool = False):
+        self.flat, self.group, self.overlap, self.comm = flat, group, overlap, comm
         self.enabled_fn = enabled_fn or (lambda: True)
         self._offsets = {id(p): off for p, off, _ in layout}
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.active = self.world > 1 or always
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if comm is not None else None
+        self.collectives = 0                      # launched so far (tests / diagnostics)
         cap = max(1, bucket_bytes // flat.element_size())
         self.buckets: List[dict] = []
         cur = None
@@ -94,8 +221,9 @@ class GradBucketReducer:
             for p in b["params"]:
                 self._of[id(p)] = b
         self._hooks = []
+        self._late: Optional[str] = None
         self.reset()
-        if overlap and self.world > 1:
+        if overlap and self.active:
             for p, _, _ in layout:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -105,14 +233,31 @@ class GradBucketReducer:
 
     def _launch(self, b):
         b["launched"] = True
-        if self.world > 1:
-            b["handle"] = dist.all_reduce(self.flat[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if not self.active:
+            return
+        self.collectives += 1
+        view = self.flat[b["lo"]:b["hi"]]
+        if self.comm is not None:
+            ready = torch.cuda.Event()
+            ready.record()                                   # on the stream that produced the bucket's last gradient
+            self.comm_stream.wait_event(ready)
+            self.comm.all_reduce(view, "sum", stream=self.comm_stream)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+            b["handle"] = done
+        else:
+            b["handle"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         if not self.enabled_fn():
             return
         b = self._of.get(id(p))
-        if b is None or b["launched"]:
+        if b is None:
+            return
+        if b["launched"]:
+            # remembered and raised from finish(): an exception inside an autograd hook would surface as an opaque engine error
+            self._late = ("a gradient arrived for a bucket that was already all-reduced in this optimizer step: run all but the last "
+                          "backward of a step under DataParallel.no_sync() (require_backward_grad_sync = False)")
             return
         if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + self.flat.element_size() * self._offsets[id(p)]:
             return      # gradient is not (yet) a view of the arena: finish() reduces the bucket after re-adoption
@@ -121,12 +266,20 @@ class GradBucketReducer:
             self._launch(b)
 
     def finish(self):
-        """Called right before the optimizer consumes the gradients: launch what is missing, wait for everything."""
+        """Called right before the optimizer consumes the gradients: launch what is missing, order the consumer behind everything."""
+        if self._late is not None:
+            msg, self._late = self._late, None
+            self.reset()
+            raise RuntimeError(msg)
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
         for b in self.buckets:
-            if b["handle"] is not None:
+            if b["handle"] is None:
+                continue
+            if self.comm is not None:
+                torch.cuda.current_stream().wait_event(b["handle"])
+            else:
                 b["handle"].wait()
         self.reset()
 
@@ -137,23 +290,48 @@ class GradBucketReducer:
 
 
 class DataParallel(nn.Module):
-    """`wrap_distributed_model` counterpart: replicas + gradient averaging.  Use `attach(optimizer)` once."""
+    """`wrap_distributed_model` counterpart: replicas + gradient averaging.  Use `attach(optimizer)` once.
 
-    def __init__(self, module: nn.Module, bucket_bytes: int = 256 << 20, group=None, broadcast: bool = True):
+    collective: "rccl" (default on a HIP device) -- the C ABI's own communicator (`RcclCommunicator`); "torch" --
+    `torch.distributed` collectives on `group` (gloo in the CPU tests).  `always_exchange` keeps the collectives running in a one-rank
+    world (they are the identity there): how the single-GPU tests drive the RCCL path."""
+
+    def __init__(self, module: nn.Module, bucket_bytes: int = 256 << 20, group=None, broadcast: bool = True,
+                 collective: Optional[str] = None, always_exchange: bool = False, comm: Optional[RcclCommunicator] = None):
         super().__init__()
         self.module = module
         self.group, self.bucket_bytes = group, bucket_bytes
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = collective or ("rccl" if comm is not None else default_collective())
+        params = list(module.parameters())
+        if self.collective == "rccl" and comm is None and not (params and params[0].is_cuda):
+            self.collective = "torch"                 # CPU modules (gloo tests): there is no RCCL without a device
+        self.comm: Optional[RcclCommunicator] = comm
+        if self.collective == "rccl" and self.comm is None:
+            self.comm = RcclCommunicator.from_process_group(params[0].device, group)
+        self.world = self.comm.world if self.comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.always_exchange = always_exchange
         self._reducer: Optional[GradBucketReducer] = None
         self._opt = None
         self.require_backward_grad_sync = True
-        if broadcast and self.world > 1:
+        if broadcast and (self.world > 1 or always_exchange):
             with torch.no_grad():                       # DDP broadcasts rank-0 weights at wrap time
                 for t in list(module.parameters()) + list(module.buffers()):
-                    dist.broadcast(t.data, src=0, group=group)
+                    if self.comm is not None:
+                        self.comm.broadcast(t.data if t.data.is_contiguous() else t.data.contiguous(), root=0)
+                    elif self.world > 1:
+                        dist.broadcast(t.data, src=0, group=group)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """DDP's context manager: backward passes inside it accumulate locally; the exchange happens on the first backward outside."""
+        old, self.require_backward_grad_sync = self.require_backward_grad_sync, False
+        try:
+            yield
+        finally:
+            self.require_backward_grad_sync = old
 
     def zero_grad(self, set_to_none: bool = False):
         if self._opt is not None:
@@ -170,67 +348,107 @@ class DataParallel(nn.Module):
         return self
 
     def _sync(self, flat: torch.Tensor, layout):
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return
         if self._reducer is None or self._reducer.flat.data_ptr() != flat.data_ptr():
             if self._reducer is not None:
                 self._reducer.remove()
             self._reducer = GradBucketReducer(flat, layout, self.bucket_bytes, self.group,
-                                              enabled_fn=lambda: self.require_backward_grad_sync)
+                                              enabled_fn=lambda: self.require_backward_grad_sync,
+                                              comm=self.comm, always=self.always_exchange)
         self._reducer.finish()
+
+    def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+        """In-place all-reduce of a small tensor (logged metrics, timing) on the same data plane as the gradients."""
+        if self.comm is not None and t.is_cuda:
+            return self.comm.all_reduce(t, op)
+        if dist.is_initialized() and self.world > 1:
+            dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=self.group)
+        return t
+
+    def close(self):
+        if self._reducer is not None:
+            self._reducer.remove()
+            self._reducer = None
+        if self.comm is not None:
+            self.comm.close()
 
 
 class GraphedTrainStep:
-    """A training step as TWO hipGraphs with the gradient exchange between them:
+    """A training step replayed from hipGraphs with the gradient exchange between them:
 
         graph A   forward, losses, backward, adoption of the stray gradients into the flat arena
-        eager     all-reduce(SUM) of the arena in `bucket_bytes` slices over RCCL   (world > 1; never captured)
-        graph B   fused AdamW (1/world folded in) 
+        exchange  all-reduce(SUM) of the arena in `bucket_bytes` slices over RCCL   (world > 1)
+        graph B   fused AdamW (1/world folded in)
 
-    The host enqueues two graph launches and a handful of collectives per step instead of ~1500 kernels, so N processes do
-    not compete for host cores; RCCL calls stay ordinary stream work, exactly as in the eager path.  (The eager path overlaps
-    the exchange with backward; here it follows backward -- 1 GB over xGMI, a few ms against a >100 ms step.)
+    The host enqueues two graph launches and one RCCL group per step instead of ~1500 kernels, so N processes do not compete for
+    host cores.  With the C ABI's communicator the slices are enqueued on the SAME stream as the graphs (`ytvln_rccl_allreduce_slices_f32`,
+    one group): plain stream order, no events, no watchdog thread.  (The eager path overlaps the exchange with backward; here it follows
+    backward -- 1 GB over xGMI, a few ms against a >100 ms step.)  mode="single" (opt-in, `YTVLN_DP_GRAPH=single`) records the exchange
+    INTO one graph with forward/backward and AdamW -- RCCL collectives are capturable -- leaving one graph launch per step.
 
     `fwd_bwd()` must run forward + backward only (utils_init.train_step(..., optimizer_step=False)) on STATIC input tensors and
     return the loss tensor; refill the inputs in place between steps.  Run >= 1 eager step first (arenas, allocator warm-up)."""
 
-    def __init__(self, model: nn.Module, optimizer, fwd_bwd: Callable[[], torch.Tensor], bucket_bytes: int = 256 << 20, group=None):
+    def __init__(self, model: nn.Module, optimizer, fwd_bwd: Callable[[], torch.Tensor], bucket_bytes: int = 256 << 20, group=None,
+                 mode: Optional[str] = None):
         self.opt, self.group, self.bucket_bytes = optimizer, group, bucket_bytes
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dp = model if isinstance(model, DataParallel) else None
+        self.comm = dp.comm if dp is not None else None
+        self.world = dp.world if dp is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.exchange = self.world > 1 or (dp is not None and dp.always_exchange)
+        self.mode = mode or os.environ.get("YTVLN_DP_GRAPH", "split")
+        if self.mode not in ("split", "single"):
+            raise ValueError(f"GraphedTrainStep mode {self.mode!r}: expected 'split' or 'single'")
+        if self.mode == "single" and self.exchange and self.comm is None:
+            raise RuntimeError("mode='single' records the exchange into the graph: it needs the RCCL communicator of the C ABI")
         if optimizer.flat_grad() is None:
             raise RuntimeError("run at least one eager training step before capturing")
         optimizer.zero_grad()
         optimizer.grad_scale = 1.0 / self.world
         torch.cuda.synchronize()
+        flat = optimizer.flat_grad()
+        cap = max(1, bucket_bytes // flat.element_size())
+        self._slices = [(lo, min(lo + cap, flat.numel())) for lo in range(0, flat.numel(), cap)]
         if dp is not None:
             dp.require_backward_grad_sync = False       # the bucket hooks must not launch collectives into the capture
+        # thread_local: with the torch.distributed data plane RCCL's watchdog thread polls events while we capture; only this
+        # thread's calls belong to the graph
         try:
-            # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
                 self.loss = fwd_bwd()
                 optimizer.capture_adopt()
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
-                optimizer.capture_update()
+                if self.mode == "single":
+                    if self.exchange:
+                        self.comm.all_reduce_slices(flat, self._slices)
+                    optimizer.capture_update()
+            self.graph_b = None
+            if self.mode == "split":
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
+                    optimizer.capture_update()
         finally:
             if dp is not None:
                 dp.require_backward_grad_sync = True
         optimizer.zero_grad()
         torch.cuda.synchronize()
-        flat = optimizer.flat_grad()
-        cap = max(1, bucket_bytes // flat.element_size())
-        self._slices = [(lo, min(lo + cap, flat.numel())) for lo in range(0, flat.numel(), cap)]
 
     def step(self, scheduler=None) -> torch.Tensor:
-        self.graph_a.replay()
-        if self.world > 1:
-            flat = self.opt.flat_grad()
-            for lo, hi in self._slices:
-                dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-        self.opt.prepare_replay()
-        self.graph_b.replay()
+        if self.mode == "single":
+            self.opt.prepare_replay()                   # hyper-parameters land (stream-ordered) before the graph's AdamW nodes
+            self.graph_a.replay()
+        else:
+            self.graph_a.replay()
+            if self.exchange:
+                flat = self.opt.flat_grad()
+                if self.comm is not None:
+                    self.comm.all_reduce_slices(flat, self._slices)
+                else:
+                    for lo, hi in self._slices:
+                        dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            self.opt.prepare_replay()
+            self.graph_b.replay()
         if scheduler is not None:
             scheduler.step()
         return self.loss

@@ -68,15 +68,22 @@ def _i64(t: Tensor, name: str) -> Tensor:
 # ------------------------------------------------------------------------------------------------------------------
 class DropoutState:
     """Philox key material for one forward pass.  `tensor` is an int64[2] DEVICE tensor (seed, counter) that the kernels
-    read; every dropout site of the pass takes the next `site` id.  Backward regenerates masks from (tensor, site)."""
+    read; every dropout site of the pass takes the next `site` id.  Backward regenerates masks from (tensor, site).
+
+    Seeding follows the reference's `set_seed` (utils/misc.py:37-45: `torch.manual_seed(seed + local_rank)`): unless
+    `manual_seed()` was called explicitly, the per-device stream is keyed by `torch.initial_seed()` at the moment the first
+    training-mode forward creates it, so different `--seed`s / ranks draw independent masks.  `get_state()` / `set_state()`
+    carry (seed, counter) through checkpoints so a resumed run continues the stream instead of replaying it."""
 
     _global = {}
-    seed = 0x5EED
+    seed = None          # None: derive from torch.initial_seed() when a device's stream is first created
 
     def __init__(self, device):
+        device = torch.device(device)
         g = DropoutState._global.get(device)
         if g is None:
-            g = torch.tensor([DropoutState.seed, 0], dtype=torch.int64, device=device)
+            seed = DropoutState.seed if DropoutState.seed is not None else (torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+            g = torch.tensor([seed, 0], dtype=torch.int64, device=device)
             DropoutState._global[device] = g
         self.tensor = g.clone()          # frozen copy for this forward (and its backward)
         g[1] += 1                        # device-side increment: graph-capturable, no host sync
@@ -87,9 +94,21 @@ class DropoutState:
         return self._site
 
     @classmethod
-    def manual_seed(cls, seed: int):
-        cls.seed = int(seed)
+    def manual_seed(cls, seed):
+        """Explicit seed for every device's stream (restarts the counters).  `None` returns to following torch.initial_seed()."""
+        cls.seed = None if seed is None else int(seed) & 0x7FFFFFFFFFFFFFFF
         cls._global.clear()
+
+    @classmethod
+    def get_state(cls) -> dict:
+        """{device string: (seed, counter)} -- one device->host read per device (checkpoint time only)."""
+        return {str(d): tuple(int(v) for v in t.tolist()) for d, t in cls._global.items()}
+
+    @classmethod
+    def set_state(cls, state: dict) -> None:
+        for d, (seed, counter) in state.items():
+            dev = torch.device(d)
+            cls._global[dev] = torch.tensor([int(seed), int(counter)], dtype=torch.int64, device=dev)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -169,6 +169,17 @@ class AdamW(Optimizer):
                                events=[None] * 4, slot=0))
         self._launch = launch
 
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces `state[p]["exp_avg"/"exp_avg_sq"]` with fresh tensors: drop the arenas so the next step rebuilds
+        them and re-adopts the LOADED moments (otherwise the kernel would keep updating the old arena while state_dict()
+        serialised the stale loaded tensors)."""
+        super().load_state_dict(state_dict)
+        # parameters / gradients keep viewing the old arenas (still valid memory) until the rebuild copies them over
+        if self._arena is not None:
+            self._written.clear()
+        self._arena = None
+        self._launch = None
+
     # ---- the step -------------------------------------------------------------------------------------------------
     def _upload_hyper(self):
         """Host -> device upload of (beta1, beta2, eps, step_size, lr) for every launch class and advance of the step

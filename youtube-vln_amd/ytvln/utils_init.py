@@ -255,8 +255,10 @@ def save_model(model_save_path, save_name, logger, model, optimizer, scheduler, 
         for k, v in list(st.items()):
             if torch.is_tensor(v):
                 st[k] = v.detach().clone()
+    # the four keys are the reference's; `ytvln_rng_state` (dropout / masking stream position) is an extra the reference ignores
     torch.save({"model_state_dict": {k: v.detach().clone() for k, v in net.state_dict().items()},
-                "optimizer_state_dict": opt_state, "scheduler_state_dict": scheduler.state_dict(), "epoch": epoch},
+                "optimizer_state_dict": opt_state, "scheduler_state_dict": scheduler.state_dict(), "epoch": epoch,
+                "ytvln_rng_state": ops.DropoutState.get_state()},
                get_model_path(model_save_path, save_name))
 
 
