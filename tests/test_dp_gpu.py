@@ -51,7 +51,8 @@ def _worker(rank, world, port, q, mode="eager"):
     D.init_distributed(backend="gloo")
     model, args = _build(dev)
     args.learning_rate = 1e-3
-    dp = D.DataParallel(model, bucket_bytes=64 << 10)          # small buckets -> several overlapped collectives
+    # collective="torch": two ranks share ONE device here, which RCCL refuses (the RCCL data plane is covered by test_rccl_gpu.py)
+    dp = D.DataParallel(model, bucket_bytes=64 << 10, collective="torch")          # small buckets -> several overlapped collectives
     opt, sched, _, _ = get_optimization(args, model, 10, None)
     dp.attach(opt)
     batch = _batch(rank, dev)

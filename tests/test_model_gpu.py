@@ -345,11 +345,9 @@ def test_optimizer_load_state_dict_after_the_arena_exists(dev, lib):
     for i in range(2):
         U.train_step(mA, oA, sA, batch, args, i, all_options=True)
     snap_model = {k: v.detach().clone() for k, v in mA.state_dict().items()}
-    snap_opt = oA.state_dict()
-    for st in snap_opt["state"].values():
-        for k, v in list(st.items()):
-            if torch.is_tensor(v):
-                st[k] = v.detach().clone()
+    live = oA.state_dict()
+    snap_opt = {"param_groups": [dict(g) for g in live["param_groups"]],
+                "state": {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in live["state"].items()}}
     snap_sched = sA.state_dict()
     U.train_step(mA, oA, sA, batch, args, 2, all_options=True)
     # run B: an optimizer that has ALREADY built its arenas on other values, then loads the snapshot
@@ -358,9 +356,9 @@ def test_optimizer_load_state_dict_after_the_arena_exists(dev, lib):
         U.train_step(mB, oB, sB, batch, args, i, all_options=True)
     mB.load_state_dict(snap_model); oB.load_state_dict(snap_opt); sB.load_state_dict(snap_sched)
     U.train_step(mB, oB, sB, batch, args, 2, all_options=True)
-    a = torch.cat([p.detach().reshape(-1) for p in mA.parameters()])
-    b = torch.cat([p.detach().reshape(-1) for p in mB.parameters()])
-    assert float((a - b).abs().max()) < 2e-6, float((a - b).abs().max())
+    bad = {n: float((pa.detach() - pb.detach()).abs().max()) for (n, pa), (_, pb) in zip(mA.named_parameters(), mB.named_parameters())
+           if float((pa.detach() - pb.detach()).abs().max()) >= 2e-6}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     sdA, sdB = oA.state_dict()["state"], oB.state_dict()["state"]
     for k in sdA:
         assert sdA[k]["step"] == sdB[k]["step"] == 3

@@ -4,6 +4,9 @@ BertBiAttention forward (fused QK^T -> softmax -> dropout -> PV kernel) for the 
 import os, sys, math
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd"))
 import torch
+from ytvln import _lib
+if os.environ.get("YTVLN_LIB"):          # experiment builds (e.g. scratch/lib_probe.so: timing probes of the attention forward)
+    _lib.LIB_PATH = os.path.abspath(os.environ["YTVLN_LIB"])
 from ytvln import ops
 dev = torch.device("cuda", 0)
 N = 56

@@ -4,22 +4,29 @@
 // (vilbert/vilbert.py:284-311, 413-440, 552-618): queries and keys/values may come from different streams (Tq != Tk) and
 // are read in place from the packed projection outputs through (pointer, leading dimension) pairs.
 //
-// Register-resident flash attention, designed around the 32x32x2 f32 MFMA fragment layout so that no score ever leaves
-// the register file and no cross-lane shuffle is needed beyond one half-wave exchange:
-//   * a wave owns 32 queries; it computes the TRANSPOSED score tile  S^T[key][query] = K . Q^T  so that the accumulator
-//     layout (column = lane&31 = query, 16 keys down the registers, the other 16 keys in the partner half-wave) makes the
-//     softmax reduction over keys a per-lane loop + one __shfl_xor(32);
-//   * the probabilities are consumed straight from those registers as the B operand of  O^T[dcol][query] += V^T . P^T,
-//     because "reg r of lane l" is exactly the (k = key, column = query) element the MFMA wants when the contraction
-//     index is visited in the permuted order key(r, half) = (r&3) + 8*(r>>2) + 4*half  (a sum is order-free);
-//   * the contraction over the head dimension is split between half-waves (half 0: dk in [0, DP/2), half 1: the rest) so
-//     each lane fetches its K operand with ds_read_b128 from an XOR-swizzled row (<= 2-way conflict, section LDS of the guide);
-//   * O^T keeps the query on the lane, so the online-softmax rescale and the final 1/l are per-lane scalars.
-// K/V tiles of 32 keys are streamed through a two-stage LDS ring by LDS-DMA, shared by the NW waves (32*NW queries) of a workgroup.
+// Register-resident flash attention built on the 32x32x2 f32 MFMA fragment layout, so that no score ever leaves the register
+// file and the softmax needs one half-wave exchange:
+//   * a wave owns 32 queries and computes the TRANSPOSED score tile  S^T[key][query] = K . Q^T : the accumulator layout
+//     (column = lane&31 = query, 16 keys down the registers, the other 16 keys in the partner half-wave) makes the reduction
+//     over keys a per-lane loop + one __shfl_xor(32);
+//   * those registers ARE the A operand of  O[query][dcol] += P[query][key] . V[key][dcol]  (lane = query row, register r = key
+//     krow(r, half) = (r&3) + 8*(r>>2) + 4*half; a sum is order-free), and the B operand is read from the V tile with ONE
+//     ds_read_b128 per key row: lane l takes the four consecutive columns 4*l .. 4*l+3, which become column l of four
+//     accumulators -- a free permutation of the output columns instead of 4 ds_read_b32 of a transposed operand;
+//   * the contraction over the head dimension of K . Q^T is split between half-waves, so the K operand is also one ds_read_b128
+//     per 4 MFMAs from an XOR-swizzled row;
+//   * O keeps the query down the registers: the (rare, lazily applied) online-softmax rescale and the final 1/l fetch the per-query
+//     scalar from the lane that owns the query with one ds_bpermute per register.
+// Occupancy is what the tiling is shaped for: <= 256 VGPRs (two waves per SIMD), K and V tiles of 32 keys in ONE
+// LDS buffer each (32 KB at d = 128) refilled by LDS-DMA in a half-tile hand-over -- the K buffer is refilled under the P.V matmul, the
+// V buffer under the next K.Q^T -- so FOUR two-wave workgroups fit a CU; a workgroup takes 32 x nw queries, waves past the end of
+// the sequence skip the matrix work (they only help with the DMA), and consecutive workgroups of one (pair, head) share an XCD.
 //
-// Backward = recompute-based flash backward split in two kernels with the same fragment tricks:
-//   dq kernel  (workgroup owns queries, loops over key tiles):  S^T, dP^T = V . dO^T, dS^T -> dQ^T += K^T . dS^T
-//   dkv kernel (workgroup owns keys,    loops over query tiles): S, dP = dO . V^T, -> dV^T += dO^T . P~, dK^T += Q^T . dS
+// Backward = recompute-based flash backward in two kernels with the same fragment tricks:
+//   dq kernel  (workgroup owns queries, loops over key tiles):  dP^T = V . dO^T, S^T = K . Q^T, dS^T -> dQ += dS . K
+//   dkv kernel (workgroup owns keys, loops over query tiles; waves work in PAIRS on one 32-key tile so that each stays under 256 VGPRs):
+//       wave 0 of the pair: S = Q . K^T -> P (sent to its partner through 4 KB of LDS), dV += P~^T . dO
+//       wave 1 of the pair: dP = dO . V^T, dS = P o (dP~ - delta), dK += dS^T . Q
 // The head dimension d may be any multiple of 4 up to 128; it is zero-padded to DP in {32, 64, 128}.
 #include "common.h"
 #include <algorithm>
@@ -50,11 +57,12 @@ __device__ __forceinline__ float score(float s, float scale, float mask) { retur
 
 // ---- LDS tile streaming ------------------------------------------------------------------------------------------------
 // A 32 x DP tile lives in LDS as S[row][DP] with the 16-byte granule g of row r stored at position g ^ (r & 7).  Tiles are
-// fed by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a two-stage ring, so the next tile is in
-// flight under the current tile's MFMAs; the DMA writes lane-linear 1 KiB pieces, so the swizzle is applied to the per-lane
-// SOURCE address.  Rows past the end / columns past d are CLAMPED to valid data (finite garbage): such keys carry a -inf
-// mask (p = 0), such queries a +inf lse (p = 0), and garbage columns only reach accumulator columns that are never stored.
-// Reads: 4 consecutive dk of one row = one ds_read_b128 (<= 2-way conflict); 32 consecutive columns of one row = ds_read_b32.
+// fed by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write); the DMA writes lane-linear 1 KiB pieces, so the swizzle
+// is applied to the per-lane SOURCE address.  Rows past the end / columns past d are CLAMPED to valid data (finite garbage): such
+// keys carry a -inf mask (p = 0), such queries a +inf lse (p = 0), and garbage columns only reach accumulator columns that are
+// never stored.
+// Reads: 4 consecutive dk of the lane's own row = one ds_read_b128 (A operand, <= 2-way conflict); DP/32 consecutive columns of a
+// row shared by a half-wave = one contiguous 128..512-byte sweep (B operand, conflict-free).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -71,27 +79,22 @@ struct Tile {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (row_base + grow) * ld + col0 + gcol), (lds_ptr_t)(S + p * 256), 16, 0, 0);
         }
     }
-    __device__ static __forceinline__ float4 row4(const float* S, int row, int gq) {
-        return *reinterpret_cast<const float4*>(S + row * DP + 4 * (gq ^ (row & 7)));
-    }
-    __device__ static __forceinline__ float elem(const float* S, int row, int col) {
-        return S[row * DP + 4 * ((col >> 2) ^ (row & 7)) + (col & 3)];
-    }
 };
 
 // Per-lane LDS offsets, computed once per kernel: the swizzle only touches the low 3 granule bits, so every fragment read
 // becomes (one of a few lane-constant bases) + (compile-time immediate).
 struct LaneOff {
-    int rows[8];   // rows[u]  : float offset of granule (u ^ (l31&7)) of row l31                      -> mma_rows
-    int cols[4];   // cols[u]  : float offset of column l31 in a row whose (row & 7) == ((u + 4*half) & 7), incl. 4*half rows -> mma_cols
+    int rows[8];   // rows[u] : float offset of granule (u ^ (l31&7)) of row l31 (this half-wave's share of the contraction) -> mma_rows
+    int brow[4];   // brow[u] : float offset of columns (DP/32)*l31 .. of the row whose (row & 7) == u + 4*half, incl. those rows -> mma_regs_rows
 };
 template <int DP>
 __device__ __forceinline__ LaneOff make_lane_off(int l31, int half) {
     LaneOff o;
 #pragma unroll
     for (int u = 0; u < 8; ++u) o.rows[u] = l31 * DP + 4 * ((half * (DP / 8) + u) ^ (l31 & 7));   // (for DP = 32 the half bit is swizzled too)
+    const int col = (DP / 32) * l31;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) o.cols[u] = (u + 4 * half) * DP + 4 * ((l31 >> 2) ^ ((u + 4 * half) & 7)) + (l31 & 3);
+    for (int u = 0; u < 4; ++u) o.brow[u] = (u + 4 * half) * DP + 4 * ((col >> 2) ^ (u + 4 * half)) + (col & 3);
     return o;
 }
 
@@ -99,6 +102,7 @@ __device__ __forceinline__ LaneOff make_lane_off(int l31, int half) {
 // s_waitcnt vmcnt(0) in front of it whenever an LDS-DMA is in flight (it might alias the DMA's destination), which drains the
 // prefetch of the next tile in the middle of the current one.
 __device__ __forceinline__ float4 lds4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float2 lds2(const float* __restrict__ p) { return *reinterpret_cast<const float2*>(p); }
 
 // per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1 (zero past nrows / past d)
 template <int DP>
@@ -125,123 +129,148 @@ __device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, floa
 }
 #define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-// acc (32x32) = Xs-tile (rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T
-template <int DP, bool BF = false>
+// acc (32x32)[tile row][lane's own row] = Xs-tile (A: rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T (B: registers)
+template <int DP, bool BF = false, bool NOLDS = false>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (BF) {
+    if constexpr (NOLDS) {          // timing probe only (YTVLN_ATTN_PROBES builds): the matrix instructions without their LDS operand reads
+#pragma unroll
+        for (int s4 = 0; s4 < DP / 2; ++s4) acc = MFMA(R[s4 ^ 1], R[s4], acc);
+        return acc;
+    } else if constexpr (BF) {
 #pragma unroll
         for (int s8 = 0; s8 < DP / 2; s8 += 8) {       // this half-wave's contraction values s8 .. s8+7 (two 16-byte granules of the row)
             const int g0 = s8 >> 2, g1 = g0 + 1;
-            const float4 x0 = *reinterpret_cast<const float4*>(Xs + lo.rows[g0 & 7] + (g0 & ~7) * 4);
-            const float4 x1 = *reinterpret_cast<const float4*>(Xs + lo.rows[g1 & 7] + (g1 & ~7) * 4);
+            const float4 x0 = lds4(Xs + lo.rows[g0 & 7] + (g0 & ~7) * 4);
+            const float4 x1 = lds4(Xs + lo.rows[g1 & 7] + (g1 & ~7) * 4);
             acc = MFMA_BF(pack8(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w),
                           pack8(R[s8], R[s8 + 1], R[s8 + 2], R[s8 + 3], R[s8 + 4], R[s8 + 5], R[s8 + 6], R[s8 + 7]), acc);
         }
         return acc;
-    }
+    } else {
 #pragma unroll
-    for (int s4 = 0; s4 < DP / 2; s4 += 4) {
-        // granule index within the half = s4/4; its low 3 bits are swizzled (lane-constant table), the rest is an immediate
-        const float4 x = *reinterpret_cast<const float4*>(Xs + lo.rows[(s4 >> 2) & 7] + ((s4 >> 2) & ~7) * 4);
-        acc = MFMA(x.x, R[s4], acc);
-        acc = MFMA(x.y, R[s4 + 1], acc);
-        acc = MFMA(x.z, R[s4 + 2], acc);
-        acc = MFMA(x.w, R[s4 + 3], acc);
+        for (int s4 = 0; s4 < DP / 2; s4 += 4) {
+            // granule index within the half = s4/4; its low 3 bits are swizzled (lane-constant table), the rest is an immediate
+            const float4 x = lds4(Xs + lo.rows[(s4 >> 2) & 7] + ((s4 >> 2) & ~7) * 4);
+            acc = MFMA(x.x, R[s4], acc);
+            acc = MFMA(x.y, R[s4 + 1], acc);
+            acc = MFMA(x.z, R[s4 + 2], acc);
+            acc = MFMA(x.w, R[s4 + 3], acc);
+        }
+        return acc;
     }
-    return acc;
 }
 
-// acc[c] (dcol x lane-col) += Xs^T (rows = dcol, contraction over the 32 tile rows in krow order) . P (own registers)
-template <int DP, bool BF = false>
-__device__ __forceinline__ void mma_cols(f32x16 (&acc)[DP / 32], const float* __restrict__ Xs, const float (&P)[16],
-                                         const LaneOff& lo, int d) {
-    if constexpr (BF) {
+// acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
+//                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
+template <int DP, bool BF = false, bool NOLDS = false>
+__device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo) {
+    constexpr int NJ = DP / 32;
+    if constexpr (NOLDS) {          // timing probe only
 #pragma unroll
-        for (int c = 0; c < DP / 32; ++c) {
-            if (c * 32 < d) {
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {      // tile rows krow(r, half), r = 8s .. 8s+7: the same order in the P registers
-                    float x[8];
+            for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r], P[r ^ 1], acc[j]);
+    } else if constexpr (BF) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = 8 * s + j;
-                        x[j] = Xs[lo.cols[r & 3] + 8 * (r >> 2) * DP + c * 32];
-                    }
-                    acc[c] = MFMA_BF(pack8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]),
-                                     pack8(P[8 * s], P[8 * s + 1], P[8 * s + 2], P[8 * s + 3], P[8 * s + 4], P[8 * s + 5], P[8 * s + 6],
-                                           P[8 * s + 7]), acc[c]);
-                }
+        for (int s = 0; s < 2; ++s) {          // tile rows krow(8s .. 8s+7, half): the order the P registers hold them
+            float x[8][NJ];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * s + i;
+                const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
+                if constexpr (NJ == 4) { const float4 v = lds4(p); x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w; }
+                else if constexpr (NJ == 2) { const float2 v = lds2(p); x[i][0] = v.x; x[i][1] = v.y; }
+                else x[i][0] = *p;
+            }
+            const bf16x8 a = pack8(P[8 * s], P[8 * s + 1], P[8 * s + 2], P[8 * s + 3], P[8 * s + 4], P[8 * s + 5], P[8 * s + 6], P[8 * s + 7]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[j] = MFMA_BF(a, pack8(x[0][j], x[1][j], x[2][j], x[3][j], x[4][j], x[5][j], x[6][j], x[7][j]), acc[j]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {         // tile row krow(r, half)
+            const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
+            if constexpr (NJ == 4) {
+                const float4 v = lds4(p);
+                acc[0] = MFMA(P[r], v.x, acc[0]); acc[1] = MFMA(P[r], v.y, acc[1]);
+                acc[2] = MFMA(P[r], v.z, acc[2]); acc[3] = MFMA(P[r], v.w, acc[3]);
+            } else if constexpr (NJ == 2) {
+                const float2 v = lds2(p);
+                acc[0] = MFMA(P[r], v.x, acc[0]); acc[1] = MFMA(P[r], v.y, acc[1]);
+            } else {
+                acc[0] = MFMA(P[r], *p, acc[0]);
             }
         }
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < DP / 32; ++c) {
-        if (c * 32 < d) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)     // row = (r&3) + 8*(r>>2) + 4*half: (row&7) only depends on (r&3, half)
-                acc[c] = MFMA(Xs[lo.cols[r & 3] + 8 * (r >> 2) * DP + c * 32], P[r], acc[c]);
-        }
     }
 }
 
-// O^T-style accumulators -> global rows (row = this lane's query/key), scaled
+// acc[j][register r <-> row krow(r, half)][column NJ*l31 + j] -> global rows row0 + krow(r, half) < nrows, columns < d, times mul
 template <int DP>
-__device__ __forceinline__ void store_cols(const f32x16 (&acc)[DP / 32], float* __restrict__ base, int64_t ld, int64_t grow,
-                                           int col0, int d, int half, float mul) {
+__device__ __forceinline__ void store_rows(const f32x16 (&acc)[DP / 32], float* __restrict__ base, int64_t ld, int64_t row_base, int row0,
+                                           int nrows, int col0, int d, int l31, int half, float mul) {
+    constexpr int NJ = DP / 32;
+    if (NJ * l31 >= d) return;
 #pragma unroll
-    for (int c = 0; c < DP / 32; ++c)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = c * 32 + 8 * g + 4 * half;
-            if (col < d)
-                *reinterpret_cast<float4*>(base + grow * ld + col0 + col) =
-                    make_float4(acc[c][4 * g] * mul, acc[c][4 * g + 1] * mul, acc[c][4 * g + 2] * mul, acc[c][4 * g + 3] * mul);
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + krow(r, half);
+        if (row < nrows) {
+            float* p = base + (row_base + row) * ld + col0 + NJ * l31;
+            if constexpr (NJ == 4) *reinterpret_cast<float4*>(p) = make_float4(acc[0][r] * mul, acc[1][r] * mul, acc[2][r] * mul, acc[3][r] * mul);
+            else if constexpr (NJ == 2) *reinterpret_cast<float2*>(p) = make_float2(acc[0][r] * mul, acc[1][r] * mul);
+            else *p = acc[0][r] * mul;
         }
+    }
 }
 
-#define TILE_WAIT_AND_SYNC()                                   \
-    do {                                                       \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
-        __builtin_amdgcn_s_barrier();                          \
+// DMA pieces issued by this wave have landed in LDS, this wave's ds_writes are done, and every wave of the workgroup got here
+#define TILE_WAIT_AND_SYNC()                                            \
+    do {                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                                   \
     } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int DP, bool DROP, bool BF>
+// forward.  LDS: [K tile][V tile][mask row, -inf past Tk].  Per key tile t:
+//     wait+barrier (K(t) landed, everyone finished P.V(t-1))  -> DMA V(t)   | S^T = K(t).Q^T, softmax
+//     wait+barrier (V(t) landed, everyone finished K(t).Q^T)  -> DMA K(t+1) | O += P.V(t)
+// PROBE (timing experiments, YTVLN_ATTN_PROBES builds only; results are wrong by construction): 1 no waits / barriers, 2 no DMA,
+// 4 no softmax arithmetic, 8 no K.Q^T matrix instructions, 16 no P.V matrix instructions, 32 matrix instructions without LDS reads.
+template <int DP, bool DROP, bool BF, int PROBE = 0>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int TS = 32 * DP;                 // floats per tile
+    constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [stage0: K V][stage1: K V][mask row, -inf past Tk]
-    float* Mrow = smem + 4 * TS;
+    float* Ks = smem;
+    float* Vs = smem + TS;
+    float* Mrow = smem + 2 * TS;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int qi = (bx * nw + wave) * 32 + l31;
+    const int q0 = (bx * nw + wave) * 32;          // this wave's queries q0 .. q0+31
+    const bool active = q0 < a.Tq;                 // wave-uniform: a wave past the end only helps with the DMA and the barriers
+    const int qi = q0 + l31;
     const bool qvalid = qi < a.Tq;
     const int col0 = h * a.d;
     const int ntiles = (a.Tk + 31) >> 5;
+    const int64_t krow_base = (int64_t)n * a.Tk;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
-    auto issue = [&](int t) {
-        float* st = smem + (t & 1) * 2 * TS;
-        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-    };
-    issue(0);                                   // first K/V tile travels while the Q fragment and the mask row are fetched
+    Tile<DP>::issue(Ks, a.k, a.ldk, krow_base, 0, a.Tk, col0, a.d, wave, nw, lane);      // K(0) travels while Q and the mask row are fetched
 
     float Qr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
-    for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[(int64_t)n * a.Tk + j] : 0.f) : -INFINITY;
+    for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
 
-    f32x16 O[DP / 32];
+    f32x16 O[NJ];
 #pragma unroll
-    for (int c = 0; c < DP / 32; ++c)
+    for (int c = 0; c < NJ; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
     float m = -INFINITY, l = 0.f;
+    float P[16];
 
     DropKey key = {0, 0, 0, 0};
     uint32_t thr = 0; float ik = 1.f;
@@ -249,54 +278,82 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
     for (int t = 0; t < ntiles; ++t) {
-        TILE_WAIT_AND_SYNC();                      // tile t landed for everyone; everyone finished reading the other stage
-        if (t + 1 < ntiles) issue(t + 1);
-        const float* Ks = smem + (t & 1) * 2 * TS;
-        const float* Vs = Ks + TS;
         const int j0 = t * 32;
-
-        const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
-        float P[16];
-        float mt = -INFINITY;
+        if constexpr (!(PROBE & 1)) TILE_WAIT_AND_SYNC();
+        if constexpr (!(PROBE & 2)) Tile<DP>::issue(Vs, a.v, a.ldv, krow_base, j0, a.Tk, col0, a.d, wave, nw, lane);
+        if (active) {
+            f32x16 S;
+            if constexpr (PROBE & 8) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
-            P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
-            P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
-        }
+                for (int r = 0; r < 16; ++r) S[r] = Qr[r] + (float)t;
+            } else {
+                S = mma_rows<DP, BF, (PROBE & 32) != 0>(Ks, Qr, lo);
+            }
+            if constexpr (PROBE & 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, P[r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        // Online softmax with a lazily moved reference point: the running reference m only moves (and O, l are only
-        // rescaled -- 64 accumulator registers through the VALU) when some row's tile maximum exceeds it by more than
-        // RESCALE_THR.  Mathematically identical (any reference cancels in O / l); exp arguments stay <= RESCALE_THR.
-        if (__any(mt > m + RESCALE_THR)) {
-            const float mn = fmaxf(m, mt);
-            const float alpha = __expf(m - mn);
-            l *= alpha;
-            m = mn;
+                for (int r = 0; r < 16; ++r) P[r] = S[r];
+                l += P[0];
+            } else {
+            float mt = -INFINITY;
 #pragma unroll
-            for (int c = 0; c < DP / 32; ++c)
+            for (int g = 0; g < 4; ++g) {
+                const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
+                P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
+                P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
-        }
-        float ps = 0.f;
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, P[r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            // Online softmax with a lazily moved reference point: the running reference m only moves (and O, l are only
+            // rescaled) when some row's tile maximum exceeds it by more than RESCALE_THR.  Mathematically identical (any
+            // reference cancels in O / l); exp arguments stay <= RESCALE_THR.  O holds the query down the registers, so the
+            // per-query factor comes from the lane that owns that query (same half-wave) -- 16 ds_bpermute, a few times per kernel.
+            if (__any(mt > m + RESCALE_THR)) {
+                const float mn = fmaxf(m, mt);
+                const float alpha = __expf(m - mn);
+                l *= alpha;
+                m = mn;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
-        ps += __shfl_xor(ps, 32, 64);
-        l += ps;
-        if (DROP) {
+                for (int r = 0; r < 16; ++r) {
+                    const float ar = __shfl(alpha, krow(r, half) + 32 * half, 64);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t bits = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key);
-                P[r] = bits >= thr ? P[r] * ik : 0.f;
+                    for (int c = 0; c < NJ; ++c) O[c][r] *= ar;
+                }
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
+            ps += __shfl_xor(ps, 32, 64);
+            l += ps;
+            if (DROP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t bits = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key);
+                    P[r] = bits >= thr ? P[r] * ik : 0.f;
+                }
+            }
             }
         }
-        mma_cols<DP, BF>(O, Vs, P, lo, a.d);
+        if constexpr (!(PROBE & 1)) TILE_WAIT_AND_SYNC();
+        if constexpr (!(PROBE & 2)) {
+            if (t + 1 < ntiles) Tile<DP>::issue(Ks, a.k, a.ldk, krow_base, j0 + 32, a.Tk, col0, a.d, wave, nw, lane);
+        }
+        if constexpr (!(PROBE & 16)) {
+            if (active) mma_regs_rows<DP, BF, (PROBE & 32) != 0>(O, P, Vs, lo);
+        } else {
+            if (active) O[0][t & 15] += P[t & 15];
+        }
     }
-    if (qvalid) {
-        store_cols<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq + qi, col0, a.d, half, 1.0f / l);
-        if (half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);   // lse is reference-independent
+    if (active) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ir = __shfl(inv, krow(r, half) + 32 * half, 64);
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) O[c][r] *= ir;
+        }
+        store_rows<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, 1.0f);
+        if (qvalid && half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);   // lse is reference-independent
     }
 }
 
@@ -327,38 +384,41 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
     }
 }
 
+// dQ.  LDS as in the forward.  Per key tile t:
+//     wait+barrier (V(t) landed, everyone finished dS.K(t-1)) -> DMA K(t)   | dP^T = V(t).dO^T
+//     wait+barrier (K(t) landed, everyone finished V(t).dO^T) -> DMA V(t+1) | S^T = K(t).Q^T, dS, dQ += dS.K(t)
 template <int DP, bool DROP, bool BF>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int TS = 32 * DP;
+    constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Mrow = smem + 4 * TS;
+    float* Ks = smem;
+    float* Vs = smem + TS;
+    float* Mrow = smem + 2 * TS;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int qi = (bx * nw + wave) * 32 + l31;
+    const int q0 = (bx * nw + wave) * 32;
+    const bool active = q0 < a.Tq;
+    const int qi = q0 + l31;
     const bool qvalid = qi < a.Tq;
     const int col0 = h * a.d;
     const int ntiles = (a.Tk + 31) >> 5;
+    const int64_t krow_base = (int64_t)n * a.Tk;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
-    auto issue = [&](int t) {
-        float* st = smem + (t & 1) * 2 * TS;
-        Tile<DP>::issue(st, a.k, a.ldk, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.v, a.ldv, (int64_t)n * a.Tk, t * 32, a.Tk, col0, a.d, wave, nw, lane);
-    };
-    issue(0);                                   // first K/V tile travels while the register fragments are fetched
+    Tile<DP>::issue(Vs, a.v, a.ldv, krow_base, 0, a.Tk, col0, a.d, wave, nw, lane);      // V(0) travels while the register fragments are fetched
 
     float Qr[DP / 2], Gr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     load_rowfrag<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
-    const float lse = qvalid ? a.lse[sidx] : 0.f;
+    const float lse = qvalid ? a.lse[sidx] : INFINITY;          // a query past the end: p = exp(-inf) = 0
     const float dl = qvalid ? a.delta[sidx] : 0.f;
-    for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[(int64_t)n * a.Tk + j] : 0.f) : -INFINITY;
+    for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
 
-    f32x16 dQ[DP / 32];
+    f32x16 dQ[NJ];
 #pragma unroll
-    for (int c = 0; c < DP / 32; ++c)
+    for (int c = 0; c < NJ; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dQ[c][r] = 0.f;
 
@@ -367,60 +427,74 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     const uint32_t dlo = (uint32_t)sidx;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
+    f32x16 dP;
     for (int t = 0; t < ntiles; ++t) {
-        TILE_WAIT_AND_SYNC();
-        if (t + 1 < ntiles) issue(t + 1);
-        const float* Ks = smem + (t & 1) * 2 * TS;
-        const float* Vs = Ks + TS;
         const int j0 = t * 32;
-
-        const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
-        const f32x16 dP = mma_rows<DP, BF>(Vs, Gr, lo);
-        float dS[16];
+        TILE_WAIT_AND_SYNC();
+        Tile<DP>::issue(Ks, a.k, a.ldk, krow_base, j0, a.Tk, col0, a.d, wave, nw, lane);
+        if (active) dP = mma_rows<DP, BF>(Vs, Gr, lo);
+        TILE_WAIT_AND_SYNC();
+        if (t + 1 < ntiles) Tile<DP>::issue(Vs, a.v, a.ldv, krow_base, j0 + 32, a.Tk, col0, a.d, wave, nw, lane);
+        if (active) {
+            const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
+            float dS[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
-            const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+            for (int g = 0; g < 4; ++g) {
+                const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
+                const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = 4 * g + u;
-                const float p = __expf(score(S[r], a.scale, mkv[u]) - lse);
-                float dp = dP[r];
-                if (DROP) dp = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key) >= thr ? dp * ik : 0.f;
-                dS[r] = p * (dp - dl);
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * g + u;
+                    const float p = __expf(score(S[r], a.scale, mkv[u]) - lse);
+                    float dp = dP[r];
+                    if (DROP) dp = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key) >= thr ? dp * ik : 0.f;
+                    dS[r] = p * (dp - dl);
+                }
             }
+            mma_regs_rows<DP, BF>(dQ, dS, Ks, lo);
         }
-        mma_cols<DP, BF>(dQ, Ks, dS, lo, a.d);
     }
-    if (qvalid) store_cols<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq + qi, col0, a.d, half, a.scale);
+    if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
 }
 
-template <int DP, bool DROP, bool BF>
+// dK / dV.  A PAIR of waves owns 32 keys: wave "S" (role 0) keeps the K fragment and the dV accumulators, wave "D" (role 1) the V
+// fragment and the dK accumulators -- 128 of the 256 matrix instructions of a (query tile, key tile) pair each, and each under 256
+// VGPRs.  LDS: STAGES x [Q tile][dO tile] | pairs x [P exchange, 4 KB] | [lse row, +inf past Tq][delta row].  Per query tile t:
+//     wait+barrier (tile t landed; STAGES = 2: everyone finished tile t-1 -> DMA tile t+1 into the other stage)
+//     S-wave: S = Q.K^T -> P -> exchange buffer            D-wave: dP = dO.V^T
+//     barrier
+//     S-wave: dV += (P o keep)^T . dO                      D-wave: dS = P o (dP o keep - delta), dK += dS^T . Q
+//     (STAGES = 1: barrier, DMA tile t+1)
+template <int DP, bool DROP, bool BF, int STAGES>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int TS = 32 * DP;
+    constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [stage0: Q dO][stage1: Q dO][lse row, +inf past Tq][delta row]
-    const int nqt = (a.Tq + 31) >> 5;
-    float* Lrow = smem + 4 * TS;
-    float* Drow = Lrow + nqt * 32;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+    const int pair = wave >> 1, role = wave & 1, npairs = nw >> 1;
+    const int nqt = (a.Tq + 31) >> 5;
+    float* Xp = smem + STAGES * 2 * TS + pair * 1024;
+    float* Lrow = smem + STAGES * 2 * TS + npairs * 1024;
+    float* Drow = Lrow + nqt * 32;
     const int l31 = lane & 31, half = lane >> 5;
-    const int kj = (bx * nw + wave) * 32 + l31;    // this lane's key
+    const int k0 = (bx * npairs + pair) * 32;      // this pair's keys k0 .. k0+31
+    const bool active = k0 < a.Tk;                 // wave-uniform, the same for both waves of a pair
+    const int kj = k0 + l31;
     const bool kvalid = kj < a.Tk;
     const int col0 = h * a.d;
+    const int64_t qrow_base = (int64_t)n * a.Tq;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
     auto issue = [&](int t) {
-        float* st = smem + (t & 1) * 2 * TS;
-        Tile<DP>::issue(st, a.q, a.ldq, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.dctx, a.ldo, (int64_t)n * a.Tq, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+        float* st = smem + (STAGES == 2 ? (t & 1) : 0) * 2 * TS;
+        Tile<DP>::issue(st, a.q, a.ldq, qrow_base, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, a.dctx, a.ldo, qrow_base, t * 32, a.Tq, col0, a.d, wave, nw, lane);
     };
-    issue(0);                                   // first Q/dO tile travels while the register fragments and the lse/delta rows are fetched
+    issue(0);                                   // first Q/dO tile travels while the register fragment and the lse/delta rows are fetched
 
-    float Kr[DP / 2], Vr[DP / 2];
-    load_rowfrag<DP>(Kr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
-    load_rowfrag<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    float Fr[DP / 2];                           // K fragment (S-wave) or V fragment (D-wave)
+    if (role == 0) load_rowfrag<DP>(Fr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    else load_rowfrag<DP>(Fr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
     const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
     const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
     for (int j = tid; j < nqt * 32; j += nthr) {
@@ -428,48 +502,74 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
         Drow[j] = j < a.Tq ? a.delta[srow + j] : 0.f;
     }
 
-    f32x16 dK[DP / 32], dV[DP / 32];
+    f32x16 acc[NJ];                             // dV (S-wave) or dK (D-wave): [key (registers)][column NJ*l31 + j]
 #pragma unroll
-    for (int c = 0; c < DP / 32; ++c)
+    for (int c = 0; c < NJ; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dK[c][r] = 0.f; dV[c][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     DropKey key = {0, 0, 0, 0};
     uint32_t thr = 0; float ik = 1.f;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
 
+    float W[16];                                // S-wave: P (then P o keep); D-wave: dP (then dS)
     for (int t = 0; t < nqt; ++t) {
         TILE_WAIT_AND_SYNC();
-        if (t + 1 < nqt) issue(t + 1);
-        const float* Qs = smem + (t & 1) * 2 * TS;
+        if (STAGES == 2 && t + 1 < nqt) issue(t + 1);
+        const float* Qs = smem + (STAGES == 2 ? (t & 1) : 0) * 2 * TS;
         const float* Gs = Qs + TS;
         const int i0 = t * 32;
-
-        // S[query][key] and dP[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
-        const f32x16 S = mma_rows<DP, BF>(Qs, Kr, lo);
-        const f32x16 dP = mma_rows<DP, BF>(Gs, Vr, lo);
-        float Pt[16], dS[16];
+        if (active) {
+            if (role == 0) {
+                // S[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
+                const f32x16 S = mma_rows<DP, BF>(Qs, Fr, lo);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
-            const float4 ds = lds4(Drow + i0 + 8 * g + 4 * half);
-            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
+                    W[4 * g] = __expf(score(S[4 * g], a.scale, mk) - ls.x); W[4 * g + 1] = __expf(score(S[4 * g + 1], a.scale, mk) - ls.y);
+                    W[4 * g + 2] = __expf(score(S[4 * g + 2], a.scale, mk) - ls.z); W[4 * g + 3] = __expf(score(S[4 * g + 3], a.scale, mk) - ls.w);
+                    *reinterpret_cast<float4*>(Xp + (g * 64 + lane) * 4) = make_float4(W[4 * g], W[4 * g + 1], W[4 * g + 2], W[4 * g + 3]);
+                }
+            } else {
+                const f32x16 dP = mma_rows<DP, BF>(Gs, Fr, lo);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = 4 * g + u;
-                const float p = __expf(score(S[r], a.scale, mk) - lsv[u]);
-                float keep = 1.f;
-                if (DROP) keep = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + 8 * g + 4 * half + u), key) >= thr ? ik : 0.f;
-                Pt[r] = p * keep;
-                dS[r] = p * (dP[r] * keep - dsv[u]);
+                for (int r = 0; r < 16; ++r) W[r] = dP[r];
             }
         }
-        mma_cols<DP, BF>(dV, Gs, Pt, lo, a.d);
-        mma_cols<DP, BF>(dK, Qs, dS, lo, a.d);
+        TILE_WAIT_AND_SYNC();                   // P has been written (lgkmcnt) by the S-wave of every pair
+        if (active) {
+            if (role == 0) {
+                if (DROP) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        W[r] = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + krow(r, half)), key) >= thr ? W[r] * ik : 0.f;
+                }
+                mma_regs_rows<DP, BF>(acc, W, Gs, lo);          // dV += P~^T . dO
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 pv = lds4(Xp + (g * 64 + lane) * 4);
+                    const float4 ds = lds4(Drow + i0 + 8 * g + 4 * half);
+                    const float pvv[4] = {pv.x, pv.y, pv.z, pv.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = 4 * g + u;
+                        float dp = W[r];
+                        if (DROP) dp = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + krow(r, half)), key) >= thr ? dp * ik : 0.f;
+                        W[r] = pvv[u] * (dp - dsv[u]);
+                    }
+                }
+                mma_regs_rows<DP, BF>(acc, W, Qs, lo);          // dK += dS^T . Q
+            }
+        }
+        if (STAGES == 1 && t + 1 < nqt) {
+            __builtin_amdgcn_s_barrier();       // everyone finished tile t: its buffers may be refilled
+            issue(t + 1);
+        }
     }
-    if (kvalid) {
-        store_cols<DP>(dV, a.dv, a.lddv, (int64_t)n * a.Tk + kj, col0, a.d, half, 1.0f);
-        store_cols<DP>(dK, a.dk, a.lddk, (int64_t)n * a.Tk + kj, col0, a.d, half, a.scale);
+    if (active) {
+        if (role == 0) store_rows<DP>(acc, a.dv, a.lddv, (int64_t)n * a.Tk, k0, a.Tk, col0, a.d, l31, half, 1.0f);
+        else store_rows<DP>(acc, a.dk, a.lddk, (int64_t)n * a.Tk, k0, a.Tk, col0, a.d, l31, half, a.scale);
     }
 }
 
@@ -493,40 +593,66 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict
     }
 }
 
-// ---- kernel entry points: one problem per launch (3-D grid), or the two directions of BertBiAttention in ONE launch (1-D grid:
-// the first nb0 workgroups belong to direction 0).  The pair launch lets the hardware dispatcher fill the slots that one
-// direction's last partial round would leave idle with the other direction's workgroups.
-struct AttnPair { AttnArgs p[2]; int nb0, gx0, gx1; };
+// ---- kernel entry points: one launch covers ONE problem or the TWO directions of BertBiAttention (1-D grid: the first nb0
+// workgroups belong to problem 0).  The linear workgroup id is remapped so that consecutive ids -- the workgroups of one (pair, head),
+// which stream the same K/V (or Q/dO) rows -- run on the same XCD and share its L2; with two problems in the launch the hardware
+// dispatcher fills the slots that one direction's last partial round would leave idle with the other direction's workgroups.
+struct AttnLaunch { AttnArgs p[2]; int nb0, gx0, gx1; };
 
-#define YT_ATTN_KERNELS(NAME, BODY, LB)                                                                                  \
-    template <int DP, bool DROP, bool BF>                                                                                \
-    __global__ LB void NAME##_kernel(const AttnArgs a) { BODY<DP, DROP, BF>(a, blockIdx.x, blockIdx.y, blockIdx.z); }    \
-    template <int DP, bool DROP, bool BF>                                                                                \
-    __global__ LB void NAME##_pair_kernel(const AttnPair b) {                                                            \
-        int bid = blockIdx.x;                                                                                            \
-        if (bid < b.nb0) {                                                                                               \
-            BODY<DP, DROP, BF>(b.p[0], bid % b.gx0, (bid / b.gx0) % b.p[0].heads, bid / (b.gx0 * b.p[0].heads));         \
-        } else {                                                                                                         \
-            bid -= b.nb0;                                                                                                \
-            BODY<DP, DROP, BF>(b.p[1], bid % b.gx1, (bid / b.gx1) % b.p[1].heads, bid / (b.gx1 * b.p[1].heads));         \
-        }                                                                                                                \
-    }
-YT_ATTN_KERNELS(attn_fwd, attn_fwd_body, __launch_bounds__(256, 2))
-YT_ATTN_KERNELS(attn_bwd_dq, attn_bwd_dq_body, __launch_bounds__(256, 2))
-YT_ATTN_KERNELS(attn_bwd_dkv, attn_bwd_dkv_body, __launch_bounds__(256))
-#undef YT_ATTN_KERNELS
+#define YT_ATTN_DECODE(BODY_CALL)                                                                              \
+    const int raw = blockIdx.x;                                                                                \
+    const int which = raw < b.nb0 ? 0 : 1;                                                                     \
+    /* remapped inside the problem: every XCD gets a contiguous share of BOTH directions (their workgroups differ 3x in length) */ \
+    const int bid = which ? xcd_remap(raw - b.nb0, (int)gridDim.x - b.nb0) : xcd_remap(raw, b.nb0);            \
+    const int gx = which ? b.gx1 : b.gx0;                                                                      \
+    const AttnArgs& a = b.p[which];                                                                            \
+    const int bx = bid % gx, h = (bid / gx) % a.heads, n = bid / (gx * a.heads);                               \
+    BODY_CALL
 
+template <int DP, bool DROP, bool BF>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<DP, DROP, BF>(a, bx, h, n))); }
+#ifdef YTVLN_ATTN_PROBES
+template <int PROBE>
+__global__ __launch_bounds__(256, 2) void attn_fwd_probe_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<128, true, false, PROBE>(a, bx, h, n))); }
+#endif
+template <int DP, bool DROP, bool BF>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_body<DP, DROP, BF>(a, bx, h, n))); }
+template <int DP, bool DROP, bool BF, int STAGES>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_body<DP, DROP, BF, STAGES>(a, bx, h, n))); }
+#undef YT_ATTN_DECODE
 
-static int pick_waves(int T) {
-    // waves per workgroup (32 rows each): least padding first, then the most waves (they share the staged tiles)
-    static const int force = getenv("YTVLN_ATTN_WAVES") ? atoi(getenv("YTVLN_ATTN_WAVES")) : 0;      // experiment knob
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Waves per workgroup of the forward / dQ kernels (32 queries each).  d > 64 (256-VGPR kernels, two waves per SIMD, 33 KB of LDS): two-wave
+// workgroups -- four of them fill a CU's eight wave slots, and a sequence of 9 query tiles costs one idle wave in five workgroups.  Smaller
+// heads run three waves per SIMD, so the shape with the fewest idle waves wins (ties: more waves share a staged tile).
+static int pick_waves(int T, int d) {
+    static const int force = env_int("YTVLN_ATTN_WAVES", 0);      // experiment knob
     if (force >= 1 && force <= 4) return force;
-    int best = 1, best_pad = 1 << 30;
+    const int tiles = (int)cdiv(T, 32);
+    if (d > 64) return tiles == 1 ? 1 : 2;
+    int best = 1, best_idle = 1 << 30;
     for (int nw = 4; nw >= 1; --nw) {
-        const int pad = (int)cdiv(T, 32 * nw) * 32 * nw - T;
-        if (pad < best_pad) { best_pad = pad; best = nw; }
+        const int idle = (int)cdiv(tiles, nw) * nw - tiles;
+        if (idle < best_idle) { best_idle = idle; best = nw; }
     }
     return best;
+}
+// Pairs of waves per workgroup of the dK/dV kernel (32 keys per pair) and the number of Q/dO tile stages.
+static int pick_pairs(int T, int d) {
+    static const int force = env_int("YTVLN_ATTN_PAIRS", 0);
+    if (force >= 1 && force <= 2) return force;
+    const int tiles = (int)cdiv(T, 32);
+    if (tiles == 1) return 1;
+    return d > 64 ? 1 : 2;
+}
+static int pick_stages(int d, int npairs) {
+    static const int force = env_int("YTVLN_ATTN_DKV_STAGES", 0);
+    if (force >= 1 && force <= 2) return force;
+    return (d > 64 && npairs == 1) ? 1 : 2;
 }
 
 static int check_common(const char* who, const AttnArgs& a) {
@@ -537,33 +663,52 @@ static int check_common(const char* who, const AttnArgs& a) {
     YT_REQUIRE(((uintptr_t)a.q & 15) == 0 && ((uintptr_t)a.k & 15) == 0 && ((uintptr_t)a.v & 15) == 0, "%s: q/k/v must be 16-byte aligned", who);
     YT_REQUIRE(a.p_drop >= 0.f && a.p_drop < 1.f, "%s: p_drop out of range", who);
     YT_REQUIRE(!(a.p_drop > 0.f) || a.rng, "%s: dropout needs rng state", who);
-    YT_REQUIRE(a.N <= 65535 && a.heads <= 65535, "%s: grid too large", who);
+    YT_REQUIRE(a.Tk <= 8192 && a.Tq <= 8192, "%s: sequence too long for the LDS-resident mask / lse rows", who);
     return 0;
 }
 
-#define DISPATCH_DP_DROP_BF(KERNEL, BFV, grid, block, lds_fn, s, a)                                            \
-    do {                                                                                                     \
-        const bool drop_ = (a).p_drop > 0.f;                                                                 \
-        if ((a).d <= 32) {                                                                                   \
-            if (drop_) hipLaunchKernelGGL((KERNEL<32, true, BFV>), grid, block, lds_fn(32), s, a);           \
-            else hipLaunchKernelGGL((KERNEL<32, false, BFV>), grid, block, lds_fn(32), s, a);                \
-        } else if ((a).d <= 64) {                                                                            \
-            if (drop_) hipLaunchKernelGGL((KERNEL<64, true, BFV>), grid, block, lds_fn(64), s, a);           \
-            else hipLaunchKernelGGL((KERNEL<64, false, BFV>), grid, block, lds_fn(64), s, a);                \
-        } else {                                                                                             \
-            if (drop_) hipLaunchKernelGGL((KERNEL<128, true, BFV>), grid, block, lds_fn(128), s, a);         \
-            else hipLaunchKernelGGL((KERNEL<128, false, BFV>), grid, block, lds_fn(128), s, a);              \
-        }                                                                                                    \
-    } while (0)
-#define DISPATCH_DP_DROP(KERNEL, grid, block, lds_fn, s, a)                           \
-    do {                                                                              \
-        if ((a).bf16) DISPATCH_DP_DROP_BF(KERNEL, true, grid, block, lds_fn, s, a);   \
-        else DISPATCH_DP_DROP_BF(KERNEL, false, grid, block, lds_fn, s, a);           \
-    } while (0)
+static int dp_of(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : 128; }
 
-// dynamic LDS: the two-stage tile ring + the streamed dimension's mask row (forward / dQ) or lse and delta rows (dK/dV), staged whole
-struct LdsFwd { int rows; size_t operator()(int dp) const { return (size_t)(4 * 32 * dp + ((rows + 31) / 32) * 32) * sizeof(float); } };
-struct LdsBwd { int rows; size_t operator()(int dp) const { return (size_t)(4 * 32 * dp + 2 * ((rows + 31) / 32) * 32) * sizeof(float); } };
+// dynamic LDS (bytes)
+static size_t lds_fwd(int dp, int Tk) { return (size_t)(2 * 32 * dp + (int)cdiv(Tk, 32) * 32) * sizeof(float); }
+static size_t lds_dkv(int dp, int stages, int npairs, int Tq) {
+    return (size_t)(stages * 2 * 32 * dp + npairs * 1024 + 2 * (int)cdiv(Tq, 32) * 32) * sizeof(float);
+}
+
+#define YT_DISPATCH3(KERNEL, DPV, DROPV, BFV, ...) hipLaunchKernelGGL((KERNEL<DPV, DROPV, BFV>), __VA_ARGS__)
+#define YT_DISPATCH_DROP_BF(KERNEL, DPV, drop_, bf_, ...)                              \
+    do {                                                                               \
+        if (drop_) {                                                                   \
+            if (bf_) YT_DISPATCH3(KERNEL, DPV, true, true, __VA_ARGS__);               \
+            else YT_DISPATCH3(KERNEL, DPV, true, false, __VA_ARGS__);                  \
+        } else {                                                                       \
+            if (bf_) YT_DISPATCH3(KERNEL, DPV, false, true, __VA_ARGS__);              \
+            else YT_DISPATCH3(KERNEL, DPV, false, false, __VA_ARGS__);                 \
+        }                                                                              \
+    } while (0)
+#define YT_DISPATCH(KERNEL, dp_, drop_, bf_, ...)                                      \
+    do {                                                                               \
+        if ((dp_) == 32) YT_DISPATCH_DROP_BF(KERNEL, 32, drop_, bf_, __VA_ARGS__);     \
+        else if ((dp_) == 64) YT_DISPATCH_DROP_BF(KERNEL, 64, drop_, bf_, __VA_ARGS__);\
+        else YT_DISPATCH_DROP_BF(KERNEL, 128, drop_, bf_, __VA_ARGS__);                \
+    } while (0)
+#define YT_DKV3(ST, DPV, DROPV, BFV, ...) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, DROPV, BFV, ST>), __VA_ARGS__)
+#define YT_DKV_DROP_BF(ST, DPV, drop_, bf_, ...)                                       \
+    do {                                                                               \
+        if (drop_) {                                                                   \
+            if (bf_) YT_DKV3(ST, DPV, true, true, __VA_ARGS__);                        \
+            else YT_DKV3(ST, DPV, true, false, __VA_ARGS__);                           \
+        } else {                                                                       \
+            if (bf_) YT_DKV3(ST, DPV, false, true, __VA_ARGS__);                       \
+            else YT_DKV3(ST, DPV, false, false, __VA_ARGS__);                          \
+        }                                                                              \
+    } while (0)
+#define YT_DKV_DP(ST, dp_, drop_, bf_, ...)                                            \
+    do {                                                                               \
+        if ((dp_) == 32) YT_DKV_DROP_BF(ST, 32, drop_, bf_, __VA_ARGS__);              \
+        else if ((dp_) == 64) YT_DKV_DROP_BF(ST, 64, drop_, bf_, __VA_ARGS__);         \
+        else YT_DKV_DROP_BF(ST, 128, drop_, bf_, __VA_ARGS__);                         \
+    } while (0)
 
 }  // namespace ytvln
 
@@ -571,41 +716,107 @@ using namespace ytvln;
 
 static void launch_delta(const float* ctx, const float* dctx, int64_t ldo, float* delta, int N, int heads, int Tq, int d, hipStream_t s) {
     const int64_t total = (int64_t)N * Tq * heads;
-    {
-        const int d4 = d / 4;
-        const int lg = d4 <= 1 ? 1 : d4 <= 2 ? 2 : d4 <= 4 ? 4 : d4 <= 8 ? 8 : d4 <= 16 ? 16 : 32;
-        const dim3 dgrid((unsigned)std::min<int64_t>(cdiv(total * lg, 256), 8192));
+    const int d4 = d / 4;
+    const int lg = d4 <= 1 ? 1 : d4 <= 2 ? 2 : d4 <= 4 ? 4 : d4 <= 8 ? 8 : d4 <= 16 ? 16 : 32;
+    const dim3 dgrid((unsigned)std::min<int64_t>(cdiv(total * lg, 256), 8192));
 #define YT_DELTA(L) hipLaunchKernelGGL(attn_delta_kernel<L>, dgrid, dim3(256), 0, s, ctx, dctx, ldo, delta, N, heads, Tq, d)
-        switch (lg) {
-            case 1: YT_DELTA(1); break;
-            case 2: YT_DELTA(2); break;
-            case 4: YT_DELTA(4); break;
-            case 8: YT_DELTA(8); break;
-            case 16: YT_DELTA(16); break;
-            default: YT_DELTA(32); break;
-        }
-#undef YT_DELTA
+    switch (lg) {
+        case 1: YT_DELTA(1); break;
+        case 2: YT_DELTA(2); break;
+        case 4: YT_DELTA(4); break;
+        case 8: YT_DELTA(8); break;
+        case 16: YT_DELTA(16); break;
+        default: YT_DELTA(32); break;
     }
+#undef YT_DELTA
+}
+
+// ---- launches over one or two problems of equal (N, heads, d) ------------------------------------------------------------------
+static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
+    const AttnArgs& a0 = b.p[0];
+    const int dp = dp_of(a0.d);
+    bool drop = false;
+    int maxTq = 0, maxTk = 0;
+    for (int i = 0; i < np; ++i) {
+        if (int rc = check_common("attn_fwd", b.p[i])) return rc;
+        YT_REQUIRE(b.p[i].out && b.p[i].lse_out && ((uintptr_t)b.p[i].out & 15) == 0, "attn_fwd: ctx/lse null or misaligned");
+        drop = drop || b.p[i].p_drop > 0.f;
+        maxTq = std::max(maxTq, b.p[i].Tq); maxTk = std::max(maxTk, b.p[i].Tk);
+    }
+    const int nw = pick_waves(maxTq, a0.d);
+    b.gx0 = (int)cdiv(b.p[0].Tq, 32 * nw);
+    b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32 * nw) : 1;
+    b.nb0 = b.gx0 * a0.heads * a0.N;
+    const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
+    YT_REQUIRE(total < (1ll << 31), "attn_fwd: grid too large");
+#ifdef YTVLN_ATTN_PROBES
+    static const int probe = env_int("YTVLN_ATTN_PROBE", 0);
+    if (probe && dp == 128 && drop && !a0.bf16) {
+#define YT_PROBE(P) case P: hipLaunchKernelGGL((attn_fwd_probe_kernel<P>), dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b); break
+        switch (probe) {
+            YT_PROBE(1); YT_PROBE(2); YT_PROBE(3); YT_PROBE(4); YT_PROBE(7); YT_PROBE(8); YT_PROBE(16); YT_PROBE(24); YT_PROBE(32); YT_PROBE(35);
+            YT_PROBE(39); YT_PROBE(31);
+            default: return fail(-1, "attn_fwd: unknown probe %d", probe);
+        }
+#undef YT_PROBE
+        YT_LAUNCH_CHECK("attn_fwd probe");
+        return 0;
+    }
+#endif
+    YT_DISPATCH(attn_fwd_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
+    YT_LAUNCH_CHECK("attn_fwd");
+    return 0;
+}
+
+static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
+    const AttnArgs& a0 = b.p[0];
+    const int dp = dp_of(a0.d);
+    bool drop = false;
+    int maxTq = 0, maxTk = 0;
+    for (int i = 0; i < np; ++i) {
+        const AttnArgs& a = b.p[i];
+        if (int rc = check_common("attn_bwd", a)) return rc;
+        YT_REQUIRE(a.ctx && a.dctx && a.lse && a.delta && a.dq && a.dk && a.dv, "attn_bwd: null pointer");
+        YT_REQUIRE(a.lddq % 4 == 0 && a.lddk % 4 == 0 && a.lddv % 4 == 0, "attn_bwd: gradient leading dimensions must be multiples of 4");
+        YT_REQUIRE((((uintptr_t)a.ctx | (uintptr_t)a.dctx | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) & 15) == 0, "attn_bwd: misaligned pointer");
+        drop = drop || a.p_drop > 0.f;
+        maxTq = std::max(maxTq, a.Tq); maxTk = std::max(maxTk, a.Tk);
+    }
+    for (int i = 0; i < np; ++i) launch_delta(b.p[i].ctx, b.p[i].dctx, b.p[i].ldo, const_cast<float*>(b.p[i].delta), a0.N, a0.heads, b.p[i].Tq, a0.d, s);
+    {
+        const int nw = pick_waves(maxTq, a0.d);
+        b.gx0 = (int)cdiv(b.p[0].Tq, 32 * nw);
+        b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32 * nw) : 1;
+        b.nb0 = b.gx0 * a0.heads * a0.N;
+        const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
+        YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
+        YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
+    }
+    {
+        const int npairs = pick_pairs(maxTk, a0.d), stages = pick_stages(a0.d, npairs);
+        b.gx0 = (int)cdiv(b.p[0].Tk, 32 * npairs);
+        b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32 * npairs) : 1;
+        b.nb0 = b.gx0 * a0.heads * a0.N;
+        const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
+        YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
+        const size_t lds = lds_dkv(dp, stages, npairs, maxTq);
+        if (stages == 1) YT_DKV_DP(1, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(128 * npairs), lds, s, b);
+        else YT_DKV_DP(2, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(128 * npairs), lds, s, b);
+    }
+    YT_LAUNCH_CHECK("attn_bwd");
+    return 0;
 }
 
 static int attn_fwd_impl(int bf16, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                          const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
                          int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
-    AttnArgs a = {};
+    AttnLaunch b = {};
+    AttnArgs& a = b.p[0];
     a.bf16 = bf16;
     a.q = q; a.k = k; a.v = v; a.mask = mask; a.out = ctx; a.lse_out = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
-    if (int rc = check_common("attn_fwd", a)) return rc;
-    YT_REQUIRE(ctx && lse && ((uintptr_t)ctx & 15) == 0, "attn_fwd: ctx/lse null or misaligned");
-    const int nw = pick_waves(Tq);
-    dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
-    hipStream_t s = as_stream(stream);
-    YT_REQUIRE(Tk <= 8192 && Tq <= 8192, "attn_fwd: sequence too long for the LDS-resident mask row");
-    const LdsFwd lds_fwd{Tk};
-    DISPATCH_DP_DROP(attn_fwd_kernel, grid, block, lds_fwd, s, a);
-    YT_LAUNCH_CHECK("attn_fwd");
-    return 0;
+    return launch_fwd(b, 1, as_stream(stream));
 }
 
 extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
@@ -626,34 +837,14 @@ static int attn_bwd_impl(int bf16, const float* q, int64_t ldq, const float* k, 
                          float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
                          int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
                          int64_t site, void* stream) {
-    AttnArgs a = {};
+    AttnLaunch b = {};
+    AttnArgs& a = b.p[0];
     a.bf16 = bf16;
     a.q = q; a.k = k; a.v = v; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta;
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
-    if (int rc = check_common("attn_bwd", a)) return rc;
-    YT_REQUIRE(ctx && dctx && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
-    YT_REQUIRE(Tk <= 8192 && Tq <= 8192, "attn_bwd: sequence too long for the LDS-resident mask / lse rows");
-    YT_REQUIRE(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: gradient leading dimensions must be multiples of 4");
-    YT_REQUIRE((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0, "attn_bwd: misaligned pointer");
-    hipStream_t s = as_stream(stream);
-    const int64_t total = (int64_t)N * Tq * heads;
-    launch_delta(ctx, dctx, ldo, delta, N, heads, Tq, d, s);
-    {
-        const int nw = pick_waves(Tq);
-        dim3 grid((unsigned)cdiv(Tq, 32 * nw), heads, N), block(64 * nw);
-        const LdsFwd lds_fwd{Tk};
-        DISPATCH_DP_DROP(attn_bwd_dq_kernel, grid, block, lds_fwd, s, a);
-    }
-    {
-        const int nw = pick_waves(Tk);
-        dim3 grid((unsigned)cdiv(Tk, 32 * nw), heads, N), block(64 * nw);
-        const LdsBwd lds_bwd{Tq};
-        DISPATCH_DP_DROP(attn_bwd_dkv_kernel, grid, block, lds_bwd, s, a);
-    }
-    YT_LAUNCH_CHECK("attn_bwd");
-    return 0;
+    return launch_bwd(b, 1, as_stream(stream));
 }
 
 extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
@@ -686,104 +877,24 @@ static void fill_args(AttnArgs& a, const ytvln_attn_problem& pr, int N, int head
     a.bf16 = bf16;
 }
 
-#define DISPATCH_PAIR_BF(KERNEL, BFV, drop_, grid, block, lds, s, b)                                           \
-    do {                                                                                                     \
-        if ((b).p[0].d <= 32) {                                                                              \
-            if (drop_) hipLaunchKernelGGL((KERNEL<32, true, BFV>), grid, block, lds(32), s, b);              \
-            else hipLaunchKernelGGL((KERNEL<32, false, BFV>), grid, block, lds(32), s, b);                   \
-        } else if ((b).p[0].d <= 64) {                                                                       \
-            if (drop_) hipLaunchKernelGGL((KERNEL<64, true, BFV>), grid, block, lds(64), s, b);              \
-            else hipLaunchKernelGGL((KERNEL<64, false, BFV>), grid, block, lds(64), s, b);                   \
-        } else {                                                                                             \
-            if (drop_) hipLaunchKernelGGL((KERNEL<128, true, BFV>), grid, block, lds(128), s, b);            \
-            else hipLaunchKernelGGL((KERNEL<128, false, BFV>), grid, block, lds(128), s, b);                 \
-        }                                                                                                    \
-    } while (0)
-#define DISPATCH_PAIR(KERNEL, drop_, grid, block, lds, s, b)                              \
-    do {                                                                                  \
-        if ((b).p[0].bf16) DISPATCH_PAIR_BF(KERNEL, true, drop_, grid, block, lds, s, b); \
-        else DISPATCH_PAIR_BF(KERNEL, false, drop_, grid, block, lds, s, b);              \
-    } while (0)
-
 extern "C" int ytvln_attn_fwd_pair(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,
                                    const int64_t* rng, int bf16, void* stream) {
     YT_REQUIRE(pa && pb, "attn_fwd_pair: null problem");
-    const int nwa = pick_waves(pa->Tq), nwb = pick_waves(pb->Tq);
-    const bool dropa = pa->p_drop > 0.f, dropb = pb->p_drop > 0.f;
-    if (nwa != nwb || (bf16 && d % 8 != 0)) {       // different workgroup shapes: two ordinary launches
-        const ytvln_attn_problem* ps[2] = {pa, pb};
-        for (const ytvln_attn_problem* p : ps)
-            if (int rc = attn_fwd_impl(bf16 && d % 8 == 0, p->q, p->ldq, p->k, p->ldk, p->v, p->ldv, p->mask, p->ctx, p->ldo, p->lse, N, heads,
-                                       p->Tq, p->Tk, d, scale, p->p_drop, rng, p->site, stream))
-                return rc;
-        return 0;
-    }
-    AttnPair b;
-    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf16);
-    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf16);
-    for (int i = 0; i < 2; ++i) {
-        if (int rc = check_common("attn_fwd_pair", b.p[i])) return rc;
-        YT_REQUIRE(b.p[i].out && b.p[i].lse_out && ((uintptr_t)b.p[i].out & 15) == 0, "attn_fwd_pair: ctx/lse null or misaligned");
-        YT_REQUIRE(b.p[i].Tk <= 8192 && b.p[i].Tq <= 8192, "attn_fwd_pair: sequence too long for the LDS-resident mask row");
-    }
-    b.gx0 = (int)cdiv(pa->Tq, 32 * nwa); b.gx1 = (int)cdiv(pb->Tq, 32 * nwa);
-    b.nb0 = b.gx0 * heads * N;
-    const int64_t total = (int64_t)b.nb0 + (int64_t)b.gx1 * heads * N;
-    YT_REQUIRE(total < (1ll << 31), "attn_fwd_pair: grid too large");
-    const LdsFwd lds{std::max(pa->Tk, pb->Tk)};
-    hipStream_t s = as_stream(stream);
-    DISPATCH_PAIR(attn_fwd_pair_kernel, (dropa || dropb), dim3((unsigned)total), dim3(64 * nwa), lds, s, b);
-    YT_LAUNCH_CHECK("attn_fwd_pair");
-    return 0;
+    const int bf = (bf16 && d % 8 == 0) ? 1 : 0;
+    AttnLaunch b = {};
+    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf);
+    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf);
+    return launch_fwd(b, 2, as_stream(stream));
 }
 
 extern "C" int ytvln_attn_bwd_pair(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,
                                    const int64_t* rng, int bf16, void* stream) {
     YT_REQUIRE(pa && pb, "attn_bwd_pair: null problem");
-    const bool same = pick_waves(pa->Tq) == pick_waves(pb->Tq) && pick_waves(pa->Tk) == pick_waves(pb->Tk) && !(bf16 && d % 8 != 0);
-    if (!same) {
-        const ytvln_attn_problem* ps[2] = {pa, pb};
-        for (const ytvln_attn_problem* p : ps)
-            if (int rc = attn_bwd_impl(bf16 && d % 8 == 0, p->q, p->ldq, p->k, p->ldk, p->v, p->ldv, p->mask, p->ctx_in, p->dctx, p->ldo, p->lse_in,
-                                       p->delta, p->dq, p->lddq, p->dk, p->lddk, p->dv, p->lddv, N, heads, p->Tq, p->Tk, d, scale, p->p_drop,
-                                       rng, p->site, stream))
-                return rc;
-        return 0;
-    }
-    AttnPair b;
-    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf16);
-    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf16);
-    hipStream_t s = as_stream(stream);
-    for (int i = 0; i < 2; ++i) {
-        const AttnArgs& a = b.p[i];
-        if (int rc = check_common("attn_bwd_pair", a)) return rc;
-        YT_REQUIRE(a.ctx && a.dctx && a.lse && a.delta && a.dq && a.dk && a.dv, "attn_bwd_pair: null pointer");
-        YT_REQUIRE(a.Tk <= 8192 && a.Tq <= 8192, "attn_bwd_pair: sequence too long for the LDS-resident mask / lse rows");
-        YT_REQUIRE(a.lddq % 4 == 0 && a.lddk % 4 == 0 && a.lddv % 4 == 0, "attn_bwd_pair: gradient leading dimensions must be multiples of 4");
-        YT_REQUIRE((((uintptr_t)a.ctx | (uintptr_t)a.dctx | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) & 15) == 0, "attn_bwd_pair: misaligned pointer");
-        launch_delta(a.ctx, a.dctx, a.ldo, (i == 0 ? pa : pb)->delta, N, heads, a.Tq, d, s);
-    }
-    const bool drop = pa->p_drop > 0.f || pb->p_drop > 0.f;
-    {
-        const int nw = pick_waves(pa->Tq);
-        b.gx0 = (int)cdiv(pa->Tq, 32 * nw); b.gx1 = (int)cdiv(pb->Tq, 32 * nw);
-        b.nb0 = b.gx0 * heads * N;
-        const int64_t total = (int64_t)b.nb0 + (int64_t)b.gx1 * heads * N;
-        YT_REQUIRE(total < (1ll << 31), "attn_bwd_pair: grid too large");
-        const LdsFwd lds{std::max(pa->Tk, pb->Tk)};
-        DISPATCH_PAIR(attn_bwd_dq_pair_kernel, drop, dim3((unsigned)total), dim3(64 * nw), lds, s, b);
-    }
-    {
-        const int nw = pick_waves(pa->Tk);
-        b.gx0 = (int)cdiv(pa->Tk, 32 * nw); b.gx1 = (int)cdiv(pb->Tk, 32 * nw);
-        b.nb0 = b.gx0 * heads * N;
-        const int64_t total = (int64_t)b.nb0 + (int64_t)b.gx1 * heads * N;
-        YT_REQUIRE(total < (1ll << 31), "attn_bwd_pair: grid too large");
-        const LdsBwd lds{std::max(pa->Tq, pb->Tq)};
-        DISPATCH_PAIR(attn_bwd_dkv_pair_kernel, drop, dim3((unsigned)total), dim3(64 * nw), lds, s, b);
-    }
-    YT_LAUNCH_CHECK("attn_bwd_pair");
-    return 0;
+    const int bf = (bf16 && d % 8 == 0) ? 1 : 0;
+    AttnLaunch b = {};
+    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf);
+    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf);
+    return launch_bwd(b, 2, as_stream(stream));
 }
 
 extern "C" int ytvln_attn_probs_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* mask, const float* lse,

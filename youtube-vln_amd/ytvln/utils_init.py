@@ -250,11 +250,11 @@ def save_model(model_save_path, save_name, logger, model, optimizer, scheduler, 
         raise ValueError("Can't find the Module here")
     if logger:
         logger.info(f"saving the {save_name} model")
-    opt_state = optimizer.state_dict()
-    for st in opt_state["state"].values():
-        for k, v in list(st.items()):
-            if torch.is_tensor(v):
-                st[k] = v.detach().clone()
+    # state_dict() hands out the optimizer's LIVE per-parameter dicts (arena views): build a detached copy, never assign into them
+    live = optimizer.state_dict()
+    opt_state = {"param_groups": live["param_groups"],
+                 "state": {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                           for i, st in live["state"].items()}}
     # the four keys are the reference's; `ytvln_rng_state` (dropout / masking stream position) is an extra the reference ignores
     torch.save({"model_state_dict": {k: v.detach().clone() for k, v in net.state_dict().items()},
                 "optimizer_state_dict": opt_state, "scheduler_state_dict": scheduler.state_dict(), "epoch": epoch,
