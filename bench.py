@@ -115,9 +115,10 @@ class GemmTimer:
                 return inner(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            inner(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
+            done = inner(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
             e1.record()
             timer.records.append((e0, e1, M, N, K, int(transA), int(transB)))
+            return done
 
         ops._gemm = timed
 

@@ -70,6 +70,17 @@ int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int6
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                    float beta, float* workspace, int64_t workspace_elems, int flags, void* stream);
 
+/* ytvln_gemm_f32 that ALSO produces a_rowsum[m] = sum_k op(A)[m, k] when it can do so for free: the bias gradient of an nn.Linear
+ * (db = sum over rows of dY, vilbert.py:285-287 ... backward) rides on its weight-gradient GEMM dW = dY^T X, whose A operand is dY^T --
+ * the workgroups of the first tile column add up the fragments they feed to the matrix cores (fixed order; split-K partials are
+ * reduced in split order: deterministic).  *rowsum_done (HOST int) is set to 1 when the sums were produced -- LDS-DMA main loop,
+ * M-contiguous fp32 A (transA = 1), K % 32 == 0, no fp32x3 -- and to 0 otherwise (the caller then runs ytvln_colsum_f32).
+ * `workspace` as returned by ytvln_gemm_workspace_elems also holds the per-split partial sums. */
+int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                          int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
+                          float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done,
+                          void* stream);
+
 /* out[b, n] = sum over the b-th block of `rows_per_block` rows of x[:, n].  out is [ceil(M/rows_per_block), N] with
  * leading dimension ldo (bias gradients, position-embedding gradient, second stage of every column reduction). */
 int ytvln_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, int64_t ldo, int rows_per_block,

@@ -851,3 +851,34 @@ def test_scatter_add_rows_sorted_is_exact_and_reproducible(dev, lib):
     ref = torch.zeros(V, H, dtype=torch.float64, device=dev).index_add_(0, ids, x.double())
     ref[0] = 0
     assert float((outs[0].double() - ref).abs().max()) < 1e-4 and float(outs[0][0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,expect", [(1024, 1024, 16128, True), (768, 3072, 4480, True), (2304, 768, 4480, True), (96, 40, 160, True),
+                                           (1601, 1024, 16128, False), (64, 64, 100, False)])
+def test_gemm_rowsum_rides_on_the_weight_gradient(dev, lib, M, N, K, expect):
+    """ytvln_gemm_f32_rowsum: dW = dY^T X with db = column sums of dY produced by the same launch (split-K and unsplit plans); when the
+    launch cannot do it (M-contiguous A with M % 4 != 0 zero-padded / K % 32 != 0 -> generic kernel) it says so and the caller uses colsum.
+    Also: the product itself is unchanged by the extra output, and repeated launches are bit-identical (fixed summation order)."""
+    import ctypes
+    from ytvln import _lib, ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dY = torch.randn(K, M, generator=g).to(dev)          # A operand stored [K, M]: transA = 1
+    X = torch.randn(K, N, generator=g).to(dev)
+    ref_w = (dY.double().t() @ X.double())
+    ref_b = dY.double().sum(0)
+    outs = []
+    for rep in range(2):
+        dW = torch.empty(M, N, device=dev)
+        db = torch.full((M,), float("nan"), device=dev)
+        done = ops._gemm(dY, M, 1, X, N, 0, dW, N, M, N, K, rowsum=db)
+        assert done == expect, (done, expect)
+        close(dW, ref_w, 2e-3 * (K / 4096) ** 0.5 + 1e-4, 2e-5, "dW")
+        if done:
+            close(db, ref_b, 1e-3 * (K / 4096) ** 0.5 + 1e-5, 2e-5, "db from the GEMM")
+        else:
+            assert bool(torch.isnan(db).all())               # untouched: the caller falls back to colsum
+        outs.append((dW.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and (not expect or torch.equal(outs[0][1], outs[1][1]))
+    plain = torch.empty(M, N, device=dev)
+    ops._gemm(dY, M, 1, X, N, 0, plain, N, M, N, K)
+    assert torch.equal(plain, outs[0][0])

@@ -768,3 +768,62 @@ def test_train_epoch_loop_and_nonstrict_checkpoint(dev, lib, tmp_path):
         if k in sd:
             assert torch.equal(s2[k], v), k
     assert not torch.equal(s2["vil_logit.weight"], model.state_dict()["vil_logit.weight"])       # stayed at its own initialisation
+
+
+def test_resume_from_a_reference_written_checkpoint(dev, lib):
+    """tests/golden/g9_ref_ckpt.bin was written by the REFERENCE's save_model after two steps of the reference's own Lily + AdamW +
+    WarmupLinear (oracle/gen_golden_ckpt.py); resumed through this repo's get_optimization(--resume) the third step must land on the
+    reference's third step (parameters, both moments, step counters, learning rate, loss).  utils_init.py:277-295, vilbert_init.py:44-70."""
+    from conftest import GOLD
+    from ytvln import synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    exp = gold("g9_expected.npz")
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True, learning_rate=1e-3, resume=True,
+                   from_pretrained=os.path.join(GOLD, "g9_ref_ckpt.bin"))
+    model, _ = build_lily(dev, "micro.json", args, seed=12)          # other initial weights: everything must come from the file
+    model.train()
+    opt, sched, _, start_epoch = get_optimization(args, model, 10, None)
+    assert start_epoch == 5
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0), dev)
+    loss, _ = U.train_step(model, opt, sched, batch, args, 2, all_options=True)
+    assert abs(float(loss) - float(exp["losses"][2])) < LOSS_TOL
+    assert np.allclose(sched.get_last_lr(), exp["lr_after"], rtol=1e-12)
+    for n, p in model.named_parameters():
+        close(p, exp["p/" + n], 2e-6, 2e-5, "param " + n)
+        if "m/" + n in exp.files:
+            st = opt.state[p]
+            assert st["step"] == int(exp["step/" + n]) == 3
+            close(st["exp_avg"], exp["m/" + n], 1e-6, 1e-4, "exp_avg " + n)
+            close(st["exp_avg_sq"], exp["v/" + n], 1e-9, 1e-4, "exp_avg_sq " + n)
+        else:
+            assert p not in opt.state or "exp_avg" not in opt.state[p], n      # tensors the reference never touched got no state here either
+
+
+def test_pretrained_model_key_set_loads_like_the_reference(dev, lib):
+    """A state dict with EXACTLY the keys of the reference's BertForMultiModalPreTraining -- what the public Conceptual-Captions
+    `pretrained_model.bin` holds (README.md:80, vilbert.py:1119-1172) -- through `Lily.from_pretrained`: the same tensors get loaded and
+    the same ones stay at their initial values as when the reference's own Lily loads that file (tests/golden/g9_pretrained_keys.json)."""
+    import json
+    from conftest import GOLD
+    from ytvln import synth
+    from ytvln.lily import Lily
+    from ytvln.vilbert import BertConfig
+    rep = json.load(open(os.path.join(GOLD, "g9_pretrained_keys.json")))
+    cfg = BertConfig(**cfg_dict("micro.json", **ZERO_DROP))
+    cfg.args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    path = os.path.join(GOLD, "g9_pretrained_keys.bin")
+    W = torch.load(path, map_location="cpu")
+    assert sorted(W) == rep["pretrained_keys"]
+    lily = Lily.from_pretrained(path, cfg, default_gpu=False)
+    sd = lily.state_dict()
+    loaded = sorted(k for k in sd if k in W and torch.equal(sd[k], W[k]))
+    assert loaded == rep["lily_keys_loaded_by_reference"]
+    assert sorted(set(sd) - set(loaded)) == rep["lily_keys_left_at_init_by_reference"] == ["judge.bias", "judge.weight", "vil_logit.bias", "vil_logit.weight"]
+    assert sorted(set(W) - set(sd)) == rep["pretrained_keys_unused_by_reference"] == []
+    lily.to(dev).eval()                                   # and the loaded model runs
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0), dev)
+    from ytvln import utils_init as U
+    with torch.no_grad():
+        out = lily(*U.get_model_input(batch, True))
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())

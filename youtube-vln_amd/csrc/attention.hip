@@ -69,14 +69,16 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <int DP>
 struct Tile {
     static constexpr int PIECES = DP / 8;    // 1 KiB pieces per 32-row tile
-    __device__ static __forceinline__ void issue(float* S, const float* __restrict__ base, int64_t ld, int64_t row_base, int row0,
-                                                 int nrows, int col0, int d, int wave, int nw, int lane) {
+    // `base` already points at (first row of this (pair, head)'s sequence, first column of the head): uniform per workgroup, so the
+    // per-lane part of a source address is a 32-bit element offset (row * ld + column < 2^31 for every shape the entry points accept).
+    __device__ static __forceinline__ void issue(float* S, const float* __restrict__ base, int ld, int row0, int nrows, int d, int wave,
+                                                 int nw, int lane) {
         for (int p = wave; p < PIECES; p += nw) {          // wave-uniform
             const int off = p * 256 + 4 * lane;
             const int row = off / DP, pos = (off % DP) >> 2;
             const int g = pos ^ (row & 7);
             const int grow = min(row0 + row, nrows - 1), gcol = min(4 * g, d - 4);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (row_base + grow) * ld + col0 + gcol), (lds_ptr_t)(S + p * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (uint32_t)(grow * ld + gcol)), (lds_ptr_t)(S + p * 256), 16, 0, 0);
         }
     }
 };
@@ -130,7 +132,7 @@ __device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, floa
 #define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // acc (32x32)[tile row][lane's own row] = Xs-tile (A: rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T (B: registers)
-template <int DP, bool BF = false, bool NOLDS = false>
+template <int DP, bool BF = false, bool NOLDS = false, bool PIPE = false>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
@@ -149,6 +151,34 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
                           pack8(R[s8], R[s8 + 1], R[s8 + 2], R[s8 + 3], R[s8 + 4], R[s8 + 5], R[s8 + 6], R[s8 + 7]), acc);
         }
         return acc;
+    } else if constexpr (PIPE) {
+        // LDS reads in two batches: the second batch is issued between the matrix instructions of the first, so only ONE LDS
+        // latency per call is exposed (hipcc on its own waits for every pair of reads right where it issues them).  Costs ~16 live
+        // registers more than the compiler's order: used where the register budget has room (forward kernel).
+        constexpr int NG = DP / 8, HB = NG > 4 ? NG / 2 : NG;        // granules per half-wave; batch size
+        float4 x0[HB], x1[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) x0[u] = lds4(Xs + lo.rows[u & 7] + (u & ~7) * 4);
+        __builtin_amdgcn_sched_barrier(0);          // (the scheduler would sink the reads back to their first use)
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            if (HB < NG) x1[u] = lds4(Xs + lo.rows[(u + HB) & 7] + ((u + HB) & ~7) * 4);
+            acc = MFMA(x0[u].x, R[4 * u], acc);
+            acc = MFMA(x0[u].y, R[4 * u + 1], acc);
+            acc = MFMA(x0[u].z, R[4 * u + 2], acc);
+            acc = MFMA(x0[u].w, R[4 * u + 3], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (HB < NG) {
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                acc = MFMA(x1[u].x, R[4 * (u + HB)], acc);
+                acc = MFMA(x1[u].y, R[4 * (u + HB) + 1], acc);
+                acc = MFMA(x1[u].z, R[4 * (u + HB) + 2], acc);
+                acc = MFMA(x1[u].w, R[4 * (u + HB) + 3], acc);
+            }
+        }
+        return acc;
     } else {
 #pragma unroll
         for (int s4 = 0; s4 < DP / 2; s4 += 4) {
@@ -165,7 +195,7 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 
 // acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
 //                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
-template <int DP, bool BF = false, bool NOLDS = false>
+template <int DP, bool BF = false, bool NOLDS = false, bool PIPE = false>
 __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo) {
     constexpr int NJ = DP / 32;
     if constexpr (NOLDS) {          // timing probe only
@@ -190,6 +220,29 @@ __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const floa
             for (int j = 0; j < NJ; ++j)
                 acc[j] = MFMA_BF(a, pack8(x[0][j], x[1][j], x[2][j], x[3][j], x[4][j], x[5][j], x[6][j], x[7][j]), acc[j]);
         }
+    } else if constexpr (PIPE) {
+        // tile rows krow(r, half), r = 0..15, in two batches of 8 reads (see mma_rows)
+        auto rd = [&](int r, float (&v)[NJ]) {
+            const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
+            if constexpr (NJ == 4) { const float4 t = lds4(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+            else if constexpr (NJ == 2) { const float2 t = lds2(p); v[0] = t.x; v[1] = t.y; }
+            else v[0] = *p;
+        };
+        float v0[8][NJ], v1[8][NJ];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rd(r, v0[r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            rd(r + 8, v1[r]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r], v0[r][j], acc[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r + 8], v1[r][j], acc[j]);
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {         // tile row krow(r, half)
@@ -256,9 +309,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
     const int col0 = h * a.d;
     const int ntiles = (a.Tk + 31) >> 5;
     const int64_t krow_base = (int64_t)n * a.Tk;
+    const float* __restrict__ kb = a.k + krow_base * a.ldk + col0;      // this (pair, head)'s K / V rows: uniform bases for the DMA
+    const float* __restrict__ vb = a.v + krow_base * a.ldv + col0;
+    const int ldk = (int)a.ldk, ldv = (int)a.ldv;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
-    Tile<DP>::issue(Ks, a.k, a.ldk, krow_base, 0, a.Tk, col0, a.d, wave, nw, lane);      // K(0) travels while Q and the mask row are fetched
+    Tile<DP>::issue(Ks, kb, ldk, 0, a.Tk, a.d, wave, nw, lane);      // K(0) travels while Q and the mask row are fetched
 
     float Qr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
@@ -280,14 +336,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32;
         if constexpr (!(PROBE & 1)) TILE_WAIT_AND_SYNC();
-        if constexpr (!(PROBE & 2)) Tile<DP>::issue(Vs, a.v, a.ldv, krow_base, j0, a.Tk, col0, a.d, wave, nw, lane);
+        if constexpr (!(PROBE & 2)) Tile<DP>::issue(Vs, vb, ldv, j0, a.Tk, a.d, wave, nw, lane);
         if (active) {
             f32x16 S;
             if constexpr (PROBE & 8) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[r] = Qr[r] + (float)t;
             } else {
-                S = mma_rows<DP, BF, (PROBE & 32) != 0>(Ks, Qr, lo);
+                S = mma_rows<DP, BF, (PROBE & 32) != 0, true>(Ks, Qr, lo);
             }
             if constexpr (PROBE & 4) {
 #pragma unroll
@@ -336,10 +392,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
         }
         if constexpr (!(PROBE & 1)) TILE_WAIT_AND_SYNC();
         if constexpr (!(PROBE & 2)) {
-            if (t + 1 < ntiles) Tile<DP>::issue(Ks, a.k, a.ldk, krow_base, j0 + 32, a.Tk, col0, a.d, wave, nw, lane);
+            if (t + 1 < ntiles) Tile<DP>::issue(Ks, kb, ldk, j0 + 32, a.Tk, a.d, wave, nw, lane);
         }
         if constexpr (!(PROBE & 16)) {
-            if (active) mma_regs_rows<DP, BF, (PROBE & 32) != 0>(O, P, Vs, lo);
+            if (active) mma_regs_rows<DP, BF, (PROBE & 32) != 0, true>(O, P, Vs, lo);
         } else {
             if (active) O[0][t & 15] += P[t & 15];
         }
@@ -404,9 +460,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     const int col0 = h * a.d;
     const int ntiles = (a.Tk + 31) >> 5;
     const int64_t krow_base = (int64_t)n * a.Tk;
+    const float* __restrict__ kb = a.k + krow_base * a.ldk + col0;
+    const float* __restrict__ vb = a.v + krow_base * a.ldv + col0;
+    const int ldk = (int)a.ldk, ldv = (int)a.ldv;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
-    Tile<DP>::issue(Vs, a.v, a.ldv, krow_base, 0, a.Tk, col0, a.d, wave, nw, lane);      // V(0) travels while the register fragments are fetched
+    Tile<DP>::issue(Vs, vb, ldv, 0, a.Tk, a.d, wave, nw, lane);      // V(0) travels while the register fragments are fetched
 
     float Qr[DP / 2], Gr[DP / 2];
     load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
@@ -431,10 +490,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32;
         TILE_WAIT_AND_SYNC();
-        Tile<DP>::issue(Ks, a.k, a.ldk, krow_base, j0, a.Tk, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(Ks, kb, ldk, j0, a.Tk, a.d, wave, nw, lane);
         if (active) dP = mma_rows<DP, BF>(Vs, Gr, lo);
         TILE_WAIT_AND_SYNC();
-        if (t + 1 < ntiles) Tile<DP>::issue(Vs, a.v, a.ldv, krow_base, j0 + 32, a.Tk, col0, a.d, wave, nw, lane);
+        if (t + 1 < ntiles) Tile<DP>::issue(Vs, vb, ldv, j0 + 32, a.Tk, a.d, wave, nw, lane);
         if (active) {
             const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
             float dS[16];
@@ -485,10 +544,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     const int64_t qrow_base = (int64_t)n * a.Tq;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
+    const float* __restrict__ qb = a.q + qrow_base * a.ldq + col0;      // this (pair, head)'s Q / dO rows: uniform bases for the DMA
+    const float* __restrict__ gb = a.dctx + qrow_base * a.ldo + col0;
+    const int ldq = (int)a.ldq, ldo = (int)a.ldo;
     auto issue = [&](int t) {
         float* st = smem + (STAGES == 2 ? (t & 1) : 0) * 2 * TS;
-        Tile<DP>::issue(st, a.q, a.ldq, qrow_base, t * 32, a.Tq, col0, a.d, wave, nw, lane);
-        Tile<DP>::issue(st + TS, a.dctx, a.ldo, qrow_base, t * 32, a.Tq, col0, a.d, wave, nw, lane);
+        Tile<DP>::issue(st, qb, ldq, t * 32, a.Tq, a.d, wave, nw, lane);
+        Tile<DP>::issue(st + TS, gb, ldo, t * 32, a.Tq, a.d, wave, nw, lane);
     };
     issue(0);                                   // first Q/dO tile travels while the register fragment and the lse/delta rows are fetched
 

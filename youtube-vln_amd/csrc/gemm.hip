@@ -36,6 +36,8 @@ struct GemmArgs {
     int ktail;            // 1: the last k-tile reaches past K -> M/N-contiguous operands clamp their k rows to K-1
     int* sk_flags;        // stream-K: one arrival flag per workgroup (zeroed before the launch); partials live in ws
     int x3;               // 1: fp32 operands split into three bf16 terms in registers, six bf16 MFMAs per product (YTVLN_GEMM_SPLIT_BF16X3)
+    float* asum;          // optional: asum[m] = sum_k op(A)[m, k] (bias gradient riding on the weight-gradient GEMM); M-contiguous A, LDS-DMA path only
+    float* asum_ws;       // split-K: per-split partial row sums [splits][M], reduced in a fixed order by splitk_reduce_kernel
 };
 
 constexpr int BK = 32;
@@ -423,6 +425,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Row sums of op(A) over this workgroup's k range (db = sum over rows of dY, riding on dW = dY^T X): every tile column reads the same
+    // A panel, so the workgroups of tile column 0 (and there the waves of wave column 0) add up the fragments they feed to the MFMAs.
+    const bool do_asum = !A_KC && !BF16 && !X3 && g.asum != nullptr && tc.n == 0 && (wave & 1) == 0;
+    float asum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+
     int st_in = 0;      // ring slot the next issue() fills
     auto issue = [&](int kt) {
         float* As = smem + st_in * STAGE;
@@ -508,6 +517,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             float4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
+            if constexpr (!A_KC && !BF16) {
+                if (do_asum) {             // wave-uniform: first tile column, first wave column
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) asum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
 #pragma unroll
@@ -525,6 +540,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
                     }
                 }
         }
+        }
+    }
+    if constexpr (!A_KC && !BF16 && !X3) {
+        if (do_asum) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = asum[i] + __shfl_xor(asum[i], 32, 64);        // the two half-waves own disjoint k
+                const int row = m0 + wm0 + 32 * i + l31;
+                if (half == 0 && row < g.M) {
+                    if (g.splits > 1) g.asum_ws[(int64_t)tc.split * g.M + row] = v;
+                    else g.asum[row] = v;
+                }
+            }
         }
     }
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
@@ -700,7 +728,15 @@ __global__ __launch_bounds__(512, 4) void gemm_streamk_kernel(const GemmArgs g) 
 
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
-                                                            const float* __restrict__ bias, int M, int N, int splits, float beta) {
+                                                            const float* __restrict__ bias, int M, int N, int splits, float beta,
+                                                            const float* __restrict__ asum_ws, float* __restrict__ asum) {
+    if (asum) {          // row sums of op(A) (GemmArgs::asum): same fixed order over the splits
+        for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < M; r += (int64_t)gridDim.x * 256) {
+            float acc = asum_ws[r];
+            for (int s = 1; s < splits; ++s) acc += asum_ws[(int64_t)s * M + r];
+            asum[r] = acc;
+        }
+    }
     const int n4 = (N + 3) >> 2;
     const int64_t total = (int64_t)M * N, groups = (int64_t)M * n4;
     const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
@@ -1027,14 +1063,16 @@ extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue)
     const int splits = std::max(std::max(plan_splits(M, N, K, epilogue), std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
                                                                                       plan_gemm(M, N, K, epilogue, true, false, true).splits)),
                                 plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points and the fp32x3 plans
-    int64_t need = splits > 1 ? (int64_t)splits * M * N : 0;
+    int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
     if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
     return need;
 }
 
-extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
-                              int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
-                              int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, void* stream) {
+static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                         int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
+                         int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done,
+                         void* stream) {
+    if (rowsum_done) *rowsum_done = 0;
     YT_REQUIRE(A && B && C, "gemm: null operand");
     YT_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
     YT_REQUIRE(epilogue >= YTVLN_EPI_NONE && epilogue <= YTVLN_EPI_MUL_DRELU, "gemm: bad epilogue %d", epilogue);
@@ -1050,6 +1088,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     hipStream_t s = as_stream(stream);
     g.splits = 1; g.kchunk = K; g.ws = nullptr; g.sk_flags = nullptr;
     g.x3 = (flags & YTVLN_GEMM_SPLIT_BF16X3) != 0;
+    g.asum = nullptr; g.asum_ws = nullptr;
     // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
     // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
     // B's k rows are clamped -- B must be [K,N]), and an M-contiguous A may have M % 4 != 0.
@@ -1082,10 +1121,15 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         return 0;
     }
     const int want = plan.splits;
-    if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
+    // row sums of op(A) ride on launches that take the LDS-DMA main loop with an M-contiguous fp32 A and no K tail (a clamped tail row would
+    // be counted twice); everything else reports "not done" and the caller runs ytvln_colsum_f32
+    const bool asum_ok = a_rowsum && g.fast && transA && !g.x3 && !g.ktail && K % BK == 0;
+    const int64_t m4r = (M + 3) / 4 * 4;
+    if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N + (asum_ok ? (int64_t)want * m4r : 0)) {
         g.kchunk = (int)cdiv(cdiv(K, want), BK) * BK;
         g.splits = (int)cdiv(K, g.kchunk);
         g.ws = workspace;
+        if (asum_ok) { g.asum = a_rowsum; g.asum_ws = workspace + (int64_t)g.splits * M * N; }
     } else if (want > 1) {                 // no workspace supplied: best unsplit plan
         plan.splits = 1;
         double bt = 1e30;
@@ -1095,12 +1139,14 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
         }
     }
     if (g.splits == 1) g.kchunk = std::max(g.kchunk, g.Kloop);
+    if (g.splits == 1 && asum_ok) g.asum = a_rowsum;
+    if (rowsum_done) *rowsum_done = g.asum != nullptr;
     if (g.splits > 1) {
         if (plan.tile == 4) launch_tile<256, 256>(g, transA, transB, s);
         else launch_tile<128, 128>(g, transA, transB, s);
         const int64_t total = (int64_t)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
-                           ldc, bias, M, N, g.splits, beta);
+                           ldc, bias, M, N, g.splits, beta, (const float*)g.asum_ws, g.asum);
     } else {
         g.splits = 1;
         if (plan.tile == 4) launch_tile<256, 256>(g, transA, transB, s);
@@ -1111,6 +1157,22 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
     }
     YT_LAUNCH_CHECK("gemm_f32");
     return 0;
+}
+
+extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                              int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
+                              int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, void* stream) {
+    return gemm_f32_impl(A, lda, transA, B, ldb, transB, C, ldc, bias, aux, ldaux, M, N, K, epilogue, beta, workspace, workspace_elems, flags,
+                         nullptr, nullptr, stream);
+}
+
+extern "C" int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                                     int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
+                                     int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum,
+                                     int* rowsum_done, void* stream) {
+    YT_REQUIRE(a_rowsum && rowsum_done, "gemm_f32_rowsum: null row-sum output");
+    return gemm_f32_impl(A, lda, transA, B, ldb, transB, C, ldc, bias, aux, ldaux, M, N, K, epilogue, beta, workspace, workspace_elems, flags,
+                         a_rowsum, rowsum_done, stream);
 }
 
 extern "C" int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpose, uint16_t* out, int64_t ldo, void* stream) {
@@ -1162,6 +1224,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
     g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr; g.x3 = 0;
+    g.asum = nullptr; g.asum_ws = nullptr;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
     const int want = plan_splits_bf16(M, N, K / 2, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
@@ -1174,7 +1237,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     if (g.splits > 1) {
         const int64_t total = (int64_t)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
-                           ldc, bias, M, N, g.splits, beta);
+                           ldc, bias, M, N, g.splits, beta, (const float*)nullptr, (float*)nullptr);
     }
     YT_LAUNCH_CHECK("gemm_bf16_nt");
     return 0;

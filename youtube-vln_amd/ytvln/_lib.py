@@ -32,6 +32,7 @@ class AttnProblem(C.Structure):
 SIGNATURES = {
     "ytvln_gemm_workspace_elems": [I32, I32, I32, I32],
     "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P],
+    "ytvln_gemm_f32_rowsum": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P, P, P],
     "ytvln_colsum_f32": [P, I64, I32, I32, P, I64, I32, P],
     "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
     "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],

@@ -6,6 +6,7 @@ libytvln.so.  All wrappers require CUDA(HIP) fp32 tensors -- there is no CPU or 
 from __future__ import annotations
 
 import math
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -163,9 +164,10 @@ def _bf16_eligible(M: int, N: int, K: int) -> bool:
 
 
 def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, A_staged=None,
-          B_staged=None):
+          B_staged=None, rowsum=None):
     """`A_staged` / `B_staged` = (bf16 tensor [M][K->64] / [N][K->64], ld): the operand already staged by the caller (bf16 mode only;
-    see _stage_bf16_dual)."""
+    see _stage_bf16_dual).  `rowsum` = an [M] tensor that should receive sum_k op(A)[m, k] (the bias gradient riding on a weight-gradient
+    GEMM, ytvln_gemm_f32_rowsum); returns True when the launch produced it, False when the caller has to run `colsum` itself."""
     bf16 = _bf16_eligible(M, N, K)
     Kw = (K + 63) // 64 * 32 if bf16 else K        # contraction length in 4-byte words, as the split-K planner counts it
     key = (M, N, Kw, epi)
@@ -184,11 +186,20 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
             Bb, lb = _stage_bf16(B, ldb, N, K, False) if transB else _stage_bf16(B, ldb, K, N, True)   # -> [N][Kp]
         call("ytvln_gemm_bf16_nt", _ptr(Ab), la, _ptr(Bb), lb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, M, N, la, epi, float(beta),
              _ptr(ws), need, _stream())
-        return
+        return False
     if _MATMUL_PRECISION == "fp32x3":
         flags = int(flags) | GEMM_SPLIT_BF16X3
+    if rowsum is not None and _FUSED_BIAS_GRAD:
+        done = ctypes.c_int(0)
+        call("ytvln_gemm_f32_rowsum", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
+             M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _ptr(rowsum), ctypes.byref(done), _stream())
+        return bool(done.value)
     call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
          M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _stream())
+    return False
+
+
+_FUSED_BIAS_GRAD = os.environ.get("YTVLN_FUSED_BIAS_GRAD", "1") != "0"      # experiment knob: 0 -> every bias gradient by ytvln_colsum_f32
 
 
 def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> Tensor:
@@ -363,12 +374,25 @@ def _rows_of_grad(dy: Tensor, M: int, N: int):
     return d2, N, 0, False
 
 
+def _accumulate_target(dres, M: int, K: int):
+    """The [M, K] row view of a residual-branch gradient the input-gradient GEMM may accumulate into (beta = 1), or None."""
+    if dres is None or dres.dtype != torch.float32 or not dres.is_cuda or dres.numel() != M * K or not dres.is_contiguous():
+        return None
+    return dres.view(M, K)
+
+
 class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b)  -- nn.Linear + optional erf-GELU / ReLU epilogue, all on the fp32 MFMA GEMM."""
+    """y = act(x W^T + b)  -- nn.Linear + optional erf-GELU / ReLU epilogue, all on the fp32 MFMA GEMM.
+
+    `passthrough=True` returns (y, x): the second output is x itself, to be used by the RESIDUAL connection that skips the sublayer this
+    projection opens (vilbert.py:322-325, 365-368: `LayerNorm(dropout(dense(...)) + input_tensor)`).  The residual branch's gradient then
+    arrives here as a second output gradient and the input-gradient GEMM accumulates into that buffer (beta = 1) instead of autograd
+    launching a separate elementwise add for the fan-out of x."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, passthrough=False):
         ctx.set_materialize_grads(False)
+        ctx.passthrough = bool(passthrough)
         x2, M, K, lda = _rows2d(x, "x")
         _check(weight, "weight")
         if weight.stride(-1) != 1:
@@ -393,12 +417,13 @@ class LinearFn(torch.autograd.Function):
         ctx.targets = _targets_of(weight)
         ctx.btargets = _targets_of(bias) if bias is not None else None
         ctx.save_for_backward(x2, weight, z if epi == EPI_GELU else (y if epi == EPI_RELU else None))
-        return _view_rows_as(y, ldy, tuple(x.shape[:-1]) + (N,))
+        out = _view_rows_as(y, ldy, tuple(x.shape[:-1]) + (N,))
+        return (out, x) if ctx.passthrough else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         if dy is None:
-            return None, None, None, None
+            return (dres if ctx.needs_input_grad[0] else None), None, None, None, None
         x2, weight, aux = ctx.saved_tensors
         M, N, K = ctx.dims
         if ctx.epi != EPI_NONE:
@@ -415,22 +440,42 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _bf16_eligible(M, K, N) and _bf16_eligible(N, K, M):
             st_p, st_t = _stage_bf16_dual(dy, ldy, M, N)          # dY read once for both of its roles
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags, A_staged=st_p)
-            dx = dx.view(ctx.in_shape)
+            acc = _accumulate_target(dres, M, K)
+            if acc is not None:          # dx = d(residual) + dY W, written over the residual branch's gradient
+                _gemm(dy, ldy, 0, weight, weight.stride(0), 0, acc, K, M, K, N, beta=1.0, flags=flags, A_staged=st_p)
+                dx = acc.view(ctx.in_shape)
+            else:
+                dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+                _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags, A_staged=st_p)
+                dx = dx.view(ctx.in_shape)
+                if dres is not None:
+                    dx = dx + dres.reshape(ctx.in_shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_db:
+            db = _direct_grad(ctx.btargets, (N,))
+            if db is None:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+        db_done = False
         if ctx.needs_input_grad[1]:
             dw = _direct_grad(ctx.targets, (N, K))
             if dw is None:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t, B_staged=ctx.x_t)
+            # db = column sums of dY = row sums of the A operand (dY^T) of this launch: rides on the GEMM when it can
+            db_done = _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t, B_staged=ctx.x_t,
+                            rowsum=db if want_db else None)
             ctx.x_t = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, M, N, ldy, out=_direct_grad(ctx.btargets, (N,)))
-        return dx, dw, db, None
+        if want_db and not db_done:
+            colsum(dy, M, N, ldy, out=db)
+        return dx, dw, db, None, None
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tensor:
     return LinearFn.apply(x, weight, bias, act)
+
+
+def linear_res(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tuple[Tensor, Tensor]:
+    """(linear(x, ...), x): use the second value for the residual connection around the sublayer (see LinearFn)."""
+    return LinearFn.apply(x, weight, bias, act, True)
 
 
 class FFNFn(torch.autograd.Function):
@@ -438,8 +483,9 @@ class FFNFn(torch.autograd.Function):
     Backward fuses the GELU derivative into the epilogue of the dX GEMM of the second projection."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, passthrough=False):
         ctx.set_materialize_grads(False)
+        ctx.passthrough = bool(passthrough)
         x2, M, K, lda = _rows2d(x, "x")
         I, N = w1.shape[0], w2.shape[0]
         need_grad = any(ctx.needs_input_grad)
@@ -456,12 +502,13 @@ class FFNFn(torch.autograd.Function):
         ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
         ctx.targets = (_targets_of(w1), _targets_of(w2), _targets_of(b1), _targets_of(b2))
         ctx.save_for_backward(x2, w1, w2, z, h)
-        return y.view(*x.shape[:-1], N)
+        out = y.view(*x.shape[:-1], N)
+        return (out, x) if ctx.passthrough else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         if dy is None:
-            return None, None, None, None, None
+            return (dres if ctx.needs_input_grad[0] else None), None, None, None, None, None
         x2, w1, w2, z, h = ctx.saved_tensors
         M, K, I, N = ctx.dims
         dy = dy.reshape(M, N)
@@ -475,26 +522,44 @@ class FFNFn(torch.autograd.Function):
         dw2 = _direct_grad(ctx.targets[1], (N, I))
         if dw2 is None:
             dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
-        _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t, B_staged=ctx.h_t)
+        db2 = _direct_grad(ctx.targets[3], (N,))
+        if db2 is None:
+            db2 = torch.empty(N, dtype=torch.float32, device=dev)
+        if not _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t, B_staged=ctx.h_t, rowsum=db2):      # db2 rides on the dW2 GEMM
+            colsum(dy, M, N, N, out=db2)
         ctx.h_t = None
         sz_p, sz_t = _stage_bf16_dual(dz, I, M, I) if dual else (None, None)
-        db2 = colsum(dy, M, N, N, out=_direct_grad(ctx.targets[3], (N,)))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I, A_staged=sz_p)
-            dx = dx.view(ctx.in_shape)
+            acc = _accumulate_target(dres, M, K)
+            if acc is not None:          # the residual around the FFN: accumulate into its gradient (see LinearFn)
+                _gemm(dz, I, 0, w1, w1.stride(0), 0, acc, K, M, K, I, beta=1.0, A_staged=sz_p)
+                dx = acc.view(ctx.in_shape)
+            else:
+                dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+                _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I, A_staged=sz_p)
+                dx = dx.view(ctx.in_shape)
+                if dres is not None:
+                    dx = dx + dres.reshape(ctx.in_shape)
         dw1 = _direct_grad(ctx.targets[0], (I, K))
         if dw1 is None:
             dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
-        _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t, B_staged=ctx.x_t)
+        db1 = _direct_grad(ctx.targets[2], (I,))
+        if db1 is None:
+            db1 = torch.empty(I, dtype=torch.float32, device=dev)
+        if not _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t, B_staged=ctx.x_t, rowsum=db1):
+            colsum(dz, M, I, I, out=db1)
         ctx.x_t = None
-        db1 = colsum(dz, M, I, I, out=_direct_grad(ctx.targets[2], (I,)))
-        return dx, dw1, db1, dw2, db2
+        return dx, dw1, db1, dw2, db2, None
 
 
 def ffn(x, w1, b1, w2, b2) -> Tensor:
     return FFNFn.apply(x, w1, b1, w2, b2)
+
+
+def ffn_res(x, w1, b1, w2, b2) -> Tuple[Tensor, Tensor]:
+    """(ffn(x, ...), x) -- the second value feeds the residual add behind the FFN (see LinearFn)."""
+    return FFNFn.apply(x, w1, b1, w2, b2, True)
 
 
 # ------------------------------------------------------------------------------------------------------------------

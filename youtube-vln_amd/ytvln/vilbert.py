@@ -177,6 +177,11 @@ class _PackedQKV:
     def project(x, q: nn.Linear, k: nn.Linear, v: nn.Linear):
         return ops.linear(x, ops.pack_rows(q.weight, k.weight, v.weight), ops.pack_rows(q.bias, k.bias, v.bias))
 
+    @staticmethod
+    def project_res(x, q: nn.Linear, k: nn.Linear, v: nn.Linear):
+        """(q|k|v projection, x for the residual around the attention block): see ops.LinearFn(passthrough)."""
+        return ops.linear_res(x, ops.pack_rows(q.weight, k.weight, v.weight), ops.pack_rows(q.bias, k.bias, v.bias))
+
 
 class _SelfAttentionBase(nn.Module):
     """Shared forward of BertSelfAttention / BertImageSelfAttention."""
@@ -195,9 +200,16 @@ class _SelfAttentionBase(nn.Module):
         self.dropout = nn.Dropout(p_attn)
 
     def forward(self, hidden_states, attention_mask):
+        out, probs, _ = self.forward_res(hidden_states, attention_mask)
+        return out, probs
+
+    def forward_res(self, hidden_states, attention_mask):
+        """(context, probs, hidden_states-for-the-residual): the third value is what the caller's `LayerNorm(dense(context) + input)`
+        must use as `input` so that the two gradients of `hidden_states` meet inside the projection's input-gradient GEMM."""
         n, t, _ = hidden_states.shape
         mask = _mask2d(attention_mask, n, t)
-        qkv = _PackedQKV.project(hidden_states, self.query, self.key, self.value).view(n * t, 3 * self.all_head_size)
+        qkv, residual = _PackedQKV.project_res(hidden_states, self.query, self.key, self.value)
+        qkv = qkv.view(n * t, 3 * self.all_head_size)
         p = _p(self, self.dropout.p)
         st = _drop_state(self, qkv) if p > 0 else None
         out, lse = ops.SelfAttentionFn.apply(qkv, mask, n, t, self.num_attention_heads, p, st.tensor if st else None,
@@ -208,7 +220,7 @@ class _SelfAttentionBase(nn.Module):
                 h = self.all_head_size
                 probs = ops.attn_probs(qkv, 0, 3 * h, qkv, h, 3 * h, mask, lse, n, self.num_attention_heads, t, t,
                                        self.attention_head_size, 1.0 / math.sqrt(self.attention_head_size))
-        return out.view(n, t, self.all_head_size), probs
+        return out.view(n, t, self.all_head_size), probs, residual
 
 
 class BertSelfAttention(_SelfAttentionBase):
@@ -241,8 +253,8 @@ class BertAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, attention_mask):
-        self_output, attention_probs = self.self(input_tensor, attention_mask)
-        return self.output(self_output, input_tensor), attention_probs
+        self_output, attention_probs, residual = self.self.forward_res(input_tensor, attention_mask)
+        return self.output(self_output, residual), attention_probs
 
 
 class _IntermediateBase(nn.Module):
@@ -280,8 +292,8 @@ class BertOutput(_OutputBase):
 def _ffn_block(inter: _IntermediateBase, out: _OutputBase, x):
     """intermediate -> output of a layer, with the two GEMMs and the GELU fused in one autograd node when possible."""
     if _act_name(inter.intermediate_act_fn) == "gelu":
-        h = ops.ffn(x, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias)
-        return _add_ln(out.LayerNorm, h, x, out, p_pre=out.dropout.p)
+        h, residual = ops.ffn_res(x, inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias)
+        return _add_ln(out.LayerNorm, h, residual, out, p_pre=out.dropout.p)
     return out(inter(x), x)
 
 
@@ -316,8 +328,8 @@ class BertImageAttention(nn.Module):
         self.output = BertImageSelfOutput(config)
 
     def forward(self, input_tensor, attention_mask):
-        self_output, attention_probs = self.self(input_tensor, attention_mask)
-        return self.output(self_output, input_tensor), attention_probs
+        self_output, attention_probs, residual = self.self.forward_res(input_tensor, attention_mask)
+        return self.output(self_output, residual), attention_probs
 
 
 class BertImageIntermediate(_IntermediateBase):
@@ -348,6 +360,7 @@ class BertBiAttention(nn.Module):
     """Cross-stream co-attention (vilbert.py:512-618).  stream 1 = vision, stream 2 = text."""
 
     want_probs = False
+    _residuals = None        # (input_tensor1, input_tensor2) as they leave the projections' autograd nodes; consumed by BertConnectionLayer
 
     def __init__(self, config):
         super().__init__()
@@ -374,12 +387,14 @@ class BertBiAttention(nn.Module):
         t = input_tensor2.shape[1]
         hb = self.all_head_size
         m1, m2 = _mask2d(attention_mask1, n, r), _mask2d(attention_mask2, n, t)
-        q1 = ops.linear(input_tensor1, self.query1.weight, self.query1.bias).view(n * r, hb)
-        kv1 = ops.linear(input_tensor1, ops.pack_rows(self.key1.weight, self.value1.weight),
-                         ops.pack_rows(self.key1.bias, self.value1.bias)).view(n * r, 2 * hb)
-        q2 = ops.linear(input_tensor2, self.query2.weight, self.query2.bias).view(n * t, hb)
-        kv2 = ops.linear(input_tensor2, ops.pack_rows(self.key2.weight, self.value2.weight),
-                         ops.pack_rows(self.key2.bias, self.value2.bias)).view(n * t, 2 * hb)
+        # each stream's input feeds two projections and the residual of BertBiOutput: the residual value travels through both
+        # projections' autograd nodes (ops.LinearFn passthrough) so the three gradients meet inside the input-gradient GEMMs
+        q1, res1 = ops.linear_res(input_tensor1, self.query1.weight, self.query1.bias)
+        kv1, res1 = ops.linear_res(res1, ops.pack_rows(self.key1.weight, self.value1.weight), ops.pack_rows(self.key1.bias, self.value1.bias))
+        q2, res2 = ops.linear_res(input_tensor2, self.query2.weight, self.query2.bias)
+        kv2, res2 = ops.linear_res(res2, ops.pack_rows(self.key2.weight, self.value2.weight), ops.pack_rows(self.key2.bias, self.value2.bias))
+        q1, kv1, q2, kv2 = q1.view(n * r, hb), kv1.view(n * r, 2 * hb), q2.view(n * t, hb), kv2.view(n * t, 2 * hb)
+        self._residuals = (res1, res2)          # picked up by BertConnectionLayer for BertBiOutput
         p1, p2 = _p(self, self.dropout1.p), _p(self, self.dropout2.p)
         st = _drop_state(self, q1) if (p1 > 0 or p2 > 0) else None
         s1, s2 = (st.next_site(), st.next_site()) if st else (0, 0)
@@ -434,7 +449,9 @@ class BertConnectionLayer(nn.Module):
         bi_output1, bi_output2, co_attention_probs = self.biattention(
             input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask, use_co_attention_mask)
         # bi_output2 (image queries over text) feeds the vision stream, bi_output1 the text stream (vilbert.py:671)
-        attention_output1, attention_output2 = self.biOutput(bi_output2, input_tensor1, bi_output1, input_tensor2)
+        res1, res2 = self.biattention._residuals
+        self.biattention._residuals = None
+        attention_output1, attention_output2 = self.biOutput(bi_output2, res1, bi_output1, res2)
         layer_output1 = _ffn_block(self.v_intermediate, self.v_output, attention_output1)
         layer_output2 = _ffn_block(self.t_intermediate, self.t_output, attention_output2)
         return layer_output1, layer_output2, co_attention_probs
