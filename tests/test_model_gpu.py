@@ -827,3 +827,109 @@ def test_pretrained_model_key_set_loads_like_the_reference(dev, lib):
     with torch.no_grad():
         out = lily(*U.get_model_input(batch, True))
     assert all(bool(torch.isfinite(v).all()) for v in out.values())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs at their FULL per-GPU sizes on the FULL model (goldens: oracle/gen_golden_full.py, real reference == oracle)
+# ------------------------------------------------------------------------------------------------------------------
+FULL_CFG = "bert_base_6_layer_6_connect.json"
+PRETRAIN = dict(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+
+
+def _bf16_check(model, batch, args, g):
+    """bf16 MFMA mode against an fp32 golden: losses within 2e-2 relative, gradient norms within 5 % (+1e-4), never bit-equal."""
+    from ytvln import ops
+    model.train()
+    ops.set_matmul_precision("bf16")
+    try:
+        outputs, total, per = losses_of(model, batch, args)
+        total.backward()
+    finally:
+        ops.set_matmul_precision("fp32")
+    worst = 0.0
+    for k in per:
+        if not k.startswith("correct_"):
+            ref = float(g["loss/" + k])
+            err = abs(float(per[k]) - ref) / max(abs(ref), 1e-6)
+            worst = max(worst, err)
+            assert err < 2e-2, (k, float(per[k]), ref)
+    assert worst > 1e-7, "bf16 mode reproduced the fp32 losses exactly: the bf16 path did not run"
+    pd = dict(model.named_parameters())
+    assert {n for n, p in model.named_parameters() if p.grad is None} == set(g["unused"].tolist())
+    bad = [(n, float(pd[n].grad.double().norm()), float(ref)) for n, ref in zip(g["grad_names"].tolist(), g["grad_norms"])
+           if abs(float(pd[n].grad.double().norm()) - ref) > 5e-2 * ref + 1e-4]
+    assert not bad, bad[:5]
+
+
+def test_g10_cfg5_long_trajectories_full_model_fp32_and_bf16(dev, lib):
+    """BASELINE configs[4]: FULL 12/6/6 model, 16 frames x 36 = 576 regions per pair, T = 80, N = 14 rows, all four losses.
+    fp32: the 1e-4 bar (losses, logit slices, gradient norms, post-AdamW parameters).  bf16 MFMA mode (the arithmetic configs[4] names):
+    losses within 2e-2 relative of the fp32 reference, gradient norms within 5 %."""
+    from ytvln import synth
+    g = gold("g10_cfg5_long_n14.npz")
+    args = args_ns(**PRETRAIN)
+    kw = dict(bs=2, K=7, T=80, frames=16, boxes=36, seed=41, ignore_rank_frac=0.0)
+    model, W = build_lily(dev, FULL_CFG, args, seed=31)
+    check_summaries(model, W, synth.to_torch(synth.make_batch(**kw), dev), args, g, float(g["lr"]))
+    del model
+    torch.cuda.empty_cache()
+    model, W = build_lily(dev, FULL_CFG, args, seed=31)
+    _bf16_check(model, synth.to_torch(synth.make_batch(**kw), dev), args, g)
+
+
+def test_g11_cfg2_full_size_n56_gradients(dev, lib):
+    """BASELINE configs[1] at the size bench.py runs: bs = 8 items x K = 7 = 56 rows, T = 80, R = 288, FULL model -- losses, logit slices
+    and checksums, ALL per-tensor gradient norms and the post-AdamW parameter summaries against the reference (round 1 checked gradients
+    at N = 7 only)."""
+    from ytvln import synth
+    g = gold("g11_cfg2_full_n56.npz")
+    args = args_ns(**PRETRAIN)
+    model, W = build_lily(dev, FULL_CFG, args, seed=32)
+    batch = synth.to_torch(synth.make_batch(bs=8, K=7, T=80, frames=8, boxes=36, seed=42), dev)
+    worst = check_summaries(model, W, batch, args, g, float(g["lr"]))
+    assert worst < 2e-4
+
+
+def test_g12_cfg4_finetune_full_size_n96(dev, lib):
+    """BASELINE configs[3] at its per-GPU size: train.py --ranking fine-tune, bs = 16 items x K = 6 = 96 rows, R = 7 x 36 = 252 (not a
+    multiple of the 32-row attention tiles), ranking head only -- the 1e-4 bar on the FULL model."""
+    from ytvln import synth
+    g = gold("g12_cfg4_full_n96.npz")
+    args = args_ns(ranking=True, pretrain=False, num_negatives=2)
+    model, W = build_lily(dev, FULL_CFG, args, seed=33)
+    batch = synth.to_torch(synth.make_batch(bs=16, K=6, T=80, frames=7, boxes=36, seed=43, finetune_heading=True), dev)
+    check_summaries(model, W, batch, args, g, float(g["lr"]))
+
+
+@pytest.mark.parametrize("case", ["g0", "g1", "g10", "g11", "g12"])
+def test_fp32x3_meets_the_fp32_bar_on_every_golden(dev, lib, case):
+    """the opt-in fp32x3 projections against EVERY model golden with the native path's own tolerances (g2 / g4 are
+    covered by test_g2_g4_full_model_fp32x3_meets_the_fp32_bar, g3 below)."""
+    from ytvln import ops, synth
+    ops.set_matmul_precision("fp32x3")
+    try:
+        if case == "g0":
+            test_g0_micro_everything(dev, lib)
+        elif case == "g1":
+            test_g1_tiny_masked_language(dev, lib)
+        elif case == "g10":
+            g = gold("g10_cfg5_long_n14.npz")
+            args = args_ns(**PRETRAIN)
+            model, W = build_lily(dev, FULL_CFG, args, seed=31)
+            check_summaries(model, W, synth.to_torch(synth.make_batch(bs=2, K=7, T=80, frames=16, boxes=36, seed=41, ignore_rank_frac=0.0), dev),
+                            args, g, float(g["lr"]))
+        elif case == "g11":
+            test_g11_cfg2_full_size_n56_gradients(dev, lib)
+        else:
+            test_g12_cfg4_finetune_full_size_n96(dev, lib)
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
+def test_fp32x3_multimodal_pretraining_golden(dev, lib):
+    from ytvln import ops
+    ops.set_matmul_precision("fp32x3")
+    try:
+        test_g3_multimodal_pretraining(dev, lib)
+    finally:
+        ops.set_matmul_precision("fp32")

@@ -47,6 +47,9 @@ struct AttnArgs {
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#ifndef YT_ATTN_BWD_PIPE
+#define YT_ATTN_BWD_PIPE 0      // LDS read batch of the backward kernels' matmuls (0 = compiler order; see mma_rows)
+#endif
 #define RESCALE_THR 12.0f    // e^12 ~ 1.6e5: far inside fp32 range even summed over thousands of keys
 
 __device__ __forceinline__ int krow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -132,7 +135,7 @@ __device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, floa
 #define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // acc (32x32)[tile row][lane's own row] = Xs-tile (A: rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T (B: registers)
-template <int DP, bool BF = false, bool NOLDS = false, bool PIPE = false>
+template <int DP, bool BF = false, bool NOLDS = false, int PIPE = 0>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
@@ -151,31 +154,26 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
                           pack8(R[s8], R[s8 + 1], R[s8 + 2], R[s8 + 3], R[s8 + 4], R[s8 + 5], R[s8 + 6], R[s8 + 7]), acc);
         }
         return acc;
-    } else if constexpr (PIPE) {
-        // LDS reads in two batches: the second batch is issued between the matrix instructions of the first, so only ONE LDS
-        // latency per call is exposed (hipcc on its own waits for every pair of reads right where it issues them).  Costs ~16 live
-        // registers more than the compiler's order: used where the register budget has room (forward kernel).
-        constexpr int NG = DP / 8, HB = NG > 4 ? NG / 2 : NG;        // granules per half-wave; batch size
-        float4 x0[HB], x1[HB];
+    } else if constexpr (PIPE > 0) {
+        // LDS reads in batches of PIPE granules, batch b+1 issued between the matrix instructions of batch b: one exposed LDS latency per
+        // call instead of one per pair of reads (hipcc on its own waits for every pair right where it issues it).  Costs ~2 x PIPE live
+        // registers more than the compiler's order: 8 in the forward kernel, 4 where the register budget is tight.
+        constexpr int NG = DP / 8, HB = NG > PIPE ? PIPE : NG, NB = NG / HB;      // granules per half-wave; batch size; batches
+        float4 x[2][HB];
 #pragma unroll
-        for (int u = 0; u < HB; ++u) x0[u] = lds4(Xs + lo.rows[u & 7] + (u & ~7) * 4);
+        for (int u = 0; u < HB; ++u) x[0][u] = lds4(Xs + lo.rows[u & 7] + (u & ~7) * 4);
         __builtin_amdgcn_sched_barrier(0);          // (the scheduler would sink the reads back to their first use)
 #pragma unroll
-        for (int u = 0; u < HB; ++u) {
-            if (HB < NG) x1[u] = lds4(Xs + lo.rows[(u + HB) & 7] + ((u + HB) & ~7) * 4);
-            acc = MFMA(x0[u].x, R[4 * u], acc);
-            acc = MFMA(x0[u].y, R[4 * u + 1], acc);
-            acc = MFMA(x0[u].z, R[4 * u + 2], acc);
-            acc = MFMA(x0[u].w, R[4 * u + 3], acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (HB < NG) {
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int u = 0; u < HB; ++u) {
-                acc = MFMA(x1[u].x, R[4 * (u + HB)], acc);
-                acc = MFMA(x1[u].y, R[4 * (u + HB) + 1], acc);
-                acc = MFMA(x1[u].z, R[4 * (u + HB) + 2], acc);
-                acc = MFMA(x1[u].w, R[4 * (u + HB) + 3], acc);
+                const int gi = b * HB + u;
+                if (b + 1 < NB) x[(b + 1) & 1][u] = lds4(Xs + lo.rows[(gi + HB) & 7] + ((gi + HB) & ~7) * 4);
+                acc = MFMA(x[b & 1][u].x, R[4 * gi], acc);
+                acc = MFMA(x[b & 1][u].y, R[4 * gi + 1], acc);
+                acc = MFMA(x[b & 1][u].z, R[4 * gi + 2], acc);
+                acc = MFMA(x[b & 1][u].w, R[4 * gi + 3], acc);
+                if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
             }
         }
         return acc;
@@ -195,7 +193,7 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 
 // acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
 //                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
-template <int DP, bool BF = false, bool NOLDS = false, bool PIPE = false>
+template <int DP, bool BF = false, bool NOLDS = false, int PIPE = 0>
 __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo) {
     constexpr int NJ = DP / 32;
     if constexpr (NOLDS) {          // timing probe only
@@ -220,29 +218,30 @@ __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const floa
             for (int j = 0; j < NJ; ++j)
                 acc[j] = MFMA_BF(a, pack8(x[0][j], x[1][j], x[2][j], x[3][j], x[4][j], x[5][j], x[6][j], x[7][j]), acc[j]);
         }
-    } else if constexpr (PIPE) {
-        // tile rows krow(r, half), r = 0..15, in two batches of 8 reads (see mma_rows)
+    } else if constexpr (PIPE > 0) {
+        // tile rows krow(r, half), r = 0..15, in batches of PIPE reads (see mma_rows)
+        constexpr int HB = PIPE > 16 ? 16 : PIPE, NB = 16 / HB;
         auto rd = [&](int r, float (&v)[NJ]) {
             const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
             if constexpr (NJ == 4) { const float4 t = lds4(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
             else if constexpr (NJ == 2) { const float2 t = lds2(p); v[0] = t.x; v[1] = t.y; }
             else v[0] = *p;
         };
-        float v0[8][NJ], v1[8][NJ];
+        float v[2][HB][NJ];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) rd(r, v0[r]);
+        for (int r = 0; r < HB; ++r) rd(r, v[0][r]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            rd(r + 8, v1[r]);
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r], v0[r][j], acc[j]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < HB; ++u) {
+                const int r = b * HB + u;
+                if (b + 1 < NB) rd(r + HB, v[(b + 1) & 1][u]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r], v[b & 1][u][j], acc[j]);
+                if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r + 8], v1[r][j], acc[j]);
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {         // tile row krow(r, half)
@@ -343,7 +342,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[r] = Qr[r] + (float)t;
             } else {
-                S = mma_rows<DP, BF, (PROBE & 32) != 0, true>(Ks, Qr, lo);
+                S = mma_rows<DP, BF, (PROBE & 32) != 0, 8>(Ks, Qr, lo);
             }
             if constexpr (PROBE & 4) {
 #pragma unroll
@@ -395,7 +394,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
             if (t + 1 < ntiles) Tile<DP>::issue(Ks, kb, ldk, j0 + 32, a.Tk, a.d, wave, nw, lane);
         }
         if constexpr (!(PROBE & 16)) {
-            if (active) mma_regs_rows<DP, BF, (PROBE & 32) != 0, true>(O, P, Vs, lo);
+            if (active) mma_regs_rows<DP, BF, (PROBE & 32) != 0, 8>(O, P, Vs, lo);
         } else {
             if (active) O[0][t & 15] += P[t & 15];
         }
@@ -491,11 +490,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
         const int j0 = t * 32;
         TILE_WAIT_AND_SYNC();
         Tile<DP>::issue(Ks, kb, ldk, j0, a.Tk, a.d, wave, nw, lane);
-        if (active) dP = mma_rows<DP, BF>(Vs, Gr, lo);
+        if (active) dP = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Vs, Gr, lo);
         TILE_WAIT_AND_SYNC();
         if (t + 1 < ntiles) Tile<DP>::issue(Vs, vb, ldv, j0 + 32, a.Tk, a.d, wave, nw, lane);
         if (active) {
-            const f32x16 S = mma_rows<DP, BF>(Ks, Qr, lo);
+            const f32x16 S = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Ks, Qr, lo);
             float dS[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -510,7 +509,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
                     dS[r] = p * (dp - dl);
                 }
             }
-            mma_regs_rows<DP, BF>(dQ, dS, Ks, lo);
+            mma_regs_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(dQ, dS, Ks, lo);
         }
     }
     if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
@@ -584,7 +583,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
         if (active) {
             if (role == 0) {
                 // S[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
-                const f32x16 S = mma_rows<DP, BF>(Qs, Fr, lo);
+                const f32x16 S = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Qs, Fr, lo);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
@@ -593,7 +592,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                     *reinterpret_cast<float4*>(Xp + (g * 64 + lane) * 4) = make_float4(W[4 * g], W[4 * g + 1], W[4 * g + 2], W[4 * g + 3]);
                 }
             } else {
-                const f32x16 dP = mma_rows<DP, BF>(Gs, Fr, lo);
+                const f32x16 dP = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Gs, Fr, lo);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) W[r] = dP[r];
             }
@@ -606,7 +605,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                     for (int r = 0; r < 16; ++r)
                         W[r] = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + krow(r, half)), key) >= thr ? W[r] * ik : 0.f;
                 }
-                mma_regs_rows<DP, BF>(acc, W, Gs, lo);          // dV += P~^T . dO
+                mma_regs_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(acc, W, Gs, lo);          // dV += P~^T . dO
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -621,7 +620,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                         W[r] = pvv[u] * (dp - dsv[u]);
                     }
                 }
-                mma_regs_rows<DP, BF>(acc, W, Qs, lo);          // dK += dS^T . Q
+                mma_regs_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(acc, W, Qs, lo);          // dK += dS^T . Q
             }
         }
         if (STAGES == 1 && t + 1 < nqt) {

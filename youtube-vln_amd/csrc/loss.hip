@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const float lse = block_lse(x, V, sh);
     if (threadIdx.x == 0) {
         row_lse[row] = lse;
-        row_loss[row] = (t == ignore) ? 0.f : lse - x[t];
+        // a target outside [0, V) that is not the ignore index (torch's kernel asserts): never read out of bounds, poison the loss
+        row_loss[row] = (t == ignore) ? 0.f : (t >= 0 && t < V) ? lse - x[t] : NAN;
     }
 }
 

@@ -675,7 +675,22 @@ class TextEmbedFn(torch.autograd.Function):
         return None, None, dword, dpos, dtyp, dg, db, None, None, None, None
 
 
+_CHECK_INDICES = os.environ.get("YTVLN_CHECK_INDICES", "0") != "0"
+
+
+def _check_index_range(idx: Tensor, n: int, what: str) -> None:
+    """Debug aid (YTVLN_CHECK_INDICES=1; one host sync per call): the embedding kernels gather rows by raw index like torch's own
+    kernels, which assert on the device; production keeps the sync-free path."""
+    if _CHECK_INDICES and idx.numel():
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= n:
+            raise IndexError(f"{what}: index range [{lo}, {hi}] outside the table of {n} rows")
+
+
 def text_embed(ids, type_ids, word, pos, typ, gamma, beta, eps=1e-12, p=0.0, drop: Optional[DropoutState] = None) -> Tensor:
+    _check_index_range(ids, word.shape[0], "token ids")
+    if type_ids is not None:
+        _check_index_range(type_ids, typ.shape[0], "token type ids")
     use = drop is not None and p > 0
     return TextEmbedFn.apply(ids, type_ids, word, pos, typ, gamma, beta, eps, p if use else 0.0, drop.tensor if use else None,
                              drop.next_site() if use else 0)
@@ -726,6 +741,8 @@ class ImageEmbedFn(torch.autograd.Function):
 
 
 def image_embed(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps=1e-12, p=0.0, drop: Optional[DropoutState] = None) -> Tensor:
+    if _CHECK_INDICES:
+        _check_index_range(loc[..., 11].long(), E.shape[0], "frame index (image_loc[..., 11])")
     use = drop is not None and p > 0
     return ImageEmbedFn.apply(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps, p if use else 0.0,
                               drop.tensor if use else None, drop.next_site() if use else 0)

@@ -220,6 +220,10 @@ def train_epoch(epoch, model, optimizer, scheduler, data_loader, writer, default
         loss, reduced_metrics = train_step(model, optimizer, scheduler, batch, args, step, logger, all_options)
         if default_gpu and writer is not None:
             global_step = step + epoch * len(data_loader)
+            if "head_row_overflow" in reduced_metrics and float(reduced_metrics["head_row_overflow"]) > 0:
+                # loss-aware heads (opt-in) decode a fixed number of rows; more target-carrying rows than that would be dropped from
+                # the loss -- never silently (checked here, where the step's scalars are read back anyway)
+                raise RuntimeError("loss_aware_heads: more rows carry a target than the row capacity; raise capacity_frac or use the full heads")
             total = sum(reduced_metrics["loss"].values())
             writer.add_scalar("learning_rate/train", float(scheduler.get_last_lr()[0]), global_step=global_step)
             writer.add_scalar("loss/train", float(total), global_step=global_step)
