@@ -886,8 +886,7 @@ def test_g11_cfg2_full_size_n56_gradients(dev, lib):
     args = args_ns(**PRETRAIN)
     model, W = build_lily(dev, FULL_CFG, args, seed=32)
     batch = synth.to_torch(synth.make_batch(bs=8, K=7, T=80, frames=8, boxes=36, seed=42), dev)
-    worst = check_summaries(model, W, batch, args, g, float(g["lr"]))
-    assert worst < 2e-4
+    check_summaries(model, W, batch, args, g, float(g["lr"]))      # (per-tensor bar inside: |norm - ref| <= 2e-4 ref + 1e-6)
 
 
 def test_g12_cfg4_finetune_full_size_n96(dev, lib):

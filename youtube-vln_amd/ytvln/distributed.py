@@ -317,7 +317,12 @@ class DataParallel(nn.Module):
             with torch.no_grad():                       # DDP broadcasts rank-0 weights at wrap time
                 for t in list(module.parameters()) + list(module.buffers()):
                     if self.comm is not None:
-                        self.comm.broadcast(t.data if t.data.is_contiguous() else t.data.contiguous(), root=0)
+                        if t.data.is_contiguous():
+                            self.comm.broadcast(t.data, root=0)
+                        else:                             # RCCL works in place on contiguous memory: go through a packed copy
+                            tmp = t.data.contiguous()
+                            self.comm.broadcast(tmp, root=0)
+                            t.data.copy_(tmp)
                     elif self.world > 1:
                         dist.broadcast(t.data, src=0, group=group)
 
