@@ -449,9 +449,9 @@ def main():
         ach = flop / (ms * 1e-3) / 1e12
         traffic, traffic_note = None, None
         try:     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (cannot be collected in-process)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc_summary.json")))
             traffic = pmc["kernels"]["gemm_dma"]["hbm_side_bytes_per_launch"]
-            traffic_note = "profiles/round1_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
+            traffic_note = "profiles/round2_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
         except (OSError, KeyError, ValueError):
             pass
         # fp32x3: six bf16 matrix instructions per algorithmic product -> the ceiling for algorithmic FLOPs is the bf16 peak / 6

@@ -39,11 +39,13 @@ struct AttnArgs {
     const float* q; const float* k; const float* v; const float* mask;
     const float* ctx; const float* dctx; const float* lse; const float* delta;
     float* out; float* lse_out; float* dq; float* dk; float* dv;
+    float* delta_out;  // dQ kernel: also write delta[n,h,q] = sum_c dctx * ctx (it owns the query rows; the dK/dV kernel, launched after it, reads it)
     int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     int N, heads, Tq, Tk, d;
     float scale, p_drop;
     const int64_t* rng; int64_t site;
     int bf16;          // 1: bf16 MFMA operands (ytvln_attn_*_bf16 entry points)
+    int dsplit;        // 1: single-tile two-wave workgroups run the d-split form (the launch reserved the 4 KB exchange buffer)
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -289,11 +291,21 @@ __device__ __forceinline__ void store_rows(const f32x16 (&acc)[DP / 32], float* 
 // forward.  LDS: [K tile][V tile][mask row, -inf past Tk].  Per key tile t:
 //     wait+barrier (K(t) landed, everyone finished P.V(t-1))  -> DMA V(t)   | S^T = K(t).Q^T, softmax
 //     wait+barrier (V(t) landed, everyone finished K(t).Q^T)  -> DMA K(t+1) | O += P.V(t)
+template <int DP, bool DROP>
+__device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const int bx, const int h, const int n);      // below
+
 // PROBE (timing experiments, YTVLN_ATTN_PROBES builds only; results are wrong by construction): 1 no waits / barriers, 2 no DMA,
 // 4 no softmax arithmetic, 8 no K.Q^T matrix instructions, 16 no P.V matrix instructions, 32 matrix instructions without LDS reads.
 template <int DP, bool DROP, bool BF, int PROBE = 0>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP, NJ = DP / 32;
+    if constexpr (DP == 128 && !BF && PROBE == 0) {
+        // a two-wave workgroup holding a single query tile shares it between its waves (d-split form above); workgroup-uniform
+        if (a.dsplit && blockDim.x == 128 && (bx * 2 + 1) * 32 >= a.Tq) {
+            attn_fwd_dsplit_body<DP, DROP>(a, bx, h, n);
+            return;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = smem + TS;
@@ -412,6 +424,157 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
     }
 }
 
+// ---- forward, "d-split" form for a workgroup whose two waves share ONE query tile -------------------------------------------------
+// With two-wave workgroups a sequence of 9 query tiles leaves the fifth workgroup of every (pair, head) with one tile: instead of idling,
+// its second wave takes half of the head dimension.  Wave w contracts K.Q^T over columns [w*DP/2, (w+1)*DP/2) (32 instead of 64 matrix
+// instructions), the two partial score tiles are added through a 4 KB LDS buffer (wave 1 adds and publishes, so both waves hold bit-identical
+// scores and run the same softmax), and wave w accumulates / stores output columns 4*l + 2w, 4*l + 2w + 1 (two of the four accumulators).  The
+// workgroup leaves its CU slot in ~60 % of the time of a full one, which takes the partial third round out of a 2240-workgroup launch.
+// DP = 128 and fp32 operands only (the launch reserves the exchange buffer exactly when this form can occur).
+template <int DP, bool DROP>
+__device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const int bx, const int h, const int n) {
+    constexpr int TS = 32 * DP, QN = DP / 4;         // QN: contraction values per lane (this wave's half of d, split between half-waves)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + TS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ntiles = (a.Tk + 31) >> 5;
+    float* Mrow = smem + 2 * TS;
+    float* X = Mrow + ntiles * 32;                   // [4 register groups][64 lanes] x 4 floats: the score exchange
+    const int q0 = bx * 2 * 32;
+    const int qi = q0 + l31;
+    const bool qvalid = qi < a.Tq;
+    const int col0 = h * a.d;
+    const int64_t krow_base = (int64_t)n * a.Tk;
+    const float* __restrict__ kb = a.k + krow_base * a.ldk + col0;
+    const float* __restrict__ vb = a.v + krow_base * a.ldv + col0;
+    const int ldk = (int)a.ldk, ldv = (int)a.ldv;
+    // A operand: granules w*(DP/8) + half*(DP/16) + u, u = 0..DP/16-1 (= 8 for DP = 128: exactly the three swizzled bits)
+    int arow[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) arow[u] = l31 * DP + 4 * (w * (DP / 8) + half * (DP / 16)) + 4 * (u ^ (l31 & 7));
+    const LaneOff lo = make_lane_off<DP>(l31, half);
+    const int bsel = 2 * w;                          // this wave's pair of output columns inside a lane's four
+
+    Tile<DP>::issue(Ks, kb, ldk, 0, a.Tk, a.d, w, 2, lane);
+
+    float Qr[QN];
+#pragma unroll
+    for (int s4 = 0; s4 < QN; s4 += 4) {
+        const int col = w * (DP / 2) + half * QN + s4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qvalid && col < a.d) v = *reinterpret_cast<const float4*>(a.q + ((int64_t)n * a.Tq + qi) * a.ldq + col0 + col);
+        Qr[s4] = v.x; Qr[s4 + 1] = v.y; Qr[s4 + 2] = v.z; Qr[s4 + 3] = v.w;
+    }
+    for (int j = tid; j < ntiles * 32; j += 128) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
+
+    f32x16 O[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    float P[16];
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr = 0; float ik = 1.f;
+    const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));
+    if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 32;
+        TILE_WAIT_AND_SYNC();
+        Tile<DP>::issue(Vs, vb, ldv, j0, a.Tk, a.d, w, 2, lane);
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = lds4(Ks + arow[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                S = MFMA(x[u].x, Qr[4 * u], S); S = MFMA(x[u].y, Qr[4 * u + 1], S);
+                S = MFMA(x[u].z, Qr[4 * u + 2], S); S = MFMA(x[u].w, Qr[4 * u + 3], S);
+            }
+        }
+        // partial scores: wave 0 publishes, wave 1 adds (one fixed order) and publishes the sum, wave 0 picks it up
+        if (w == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(X + (g * 64 + lane) * 4) = make_float4(S[4 * g], S[4 * g + 1], S[4 * g + 2], S[4 * g + 3]);
+        }
+        TILE_WAIT_AND_SYNC();
+        if (w == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = lds4(X + (g * 64 + lane) * 4);
+                S[4 * g] = o.x + S[4 * g]; S[4 * g + 1] = o.y + S[4 * g + 1]; S[4 * g + 2] = o.z + S[4 * g + 2]; S[4 * g + 3] = o.w + S[4 * g + 3];
+                *reinterpret_cast<float4*>(X + (g * 64 + lane) * 4) = make_float4(S[4 * g], S[4 * g + 1], S[4 * g + 2], S[4 * g + 3]);
+            }
+        }
+        TILE_WAIT_AND_SYNC();
+        if (w == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = lds4(X + (g * 64 + lane) * 4);
+                S[4 * g] = o.x; S[4 * g + 1] = o.y; S[4 * g + 2] = o.z; S[4 * g + 3] = o.w;
+            }
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
+            P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
+            P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, P[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        if (__any(mt > m + RESCALE_THR)) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = __expf(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ar = __shfl(alpha, krow(r, half) + 32 * half, 64);
+                O[0][r] *= ar; O[1][r] *= ar;
+            }
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l += ps;
+        if (DROP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t bits = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key);
+                P[r] = bits >= thr ? P[r] * ik : 0.f;
+            }
+        }
+        TILE_WAIT_AND_SYNC();
+        if (t + 1 < ntiles) Tile<DP>::issue(Ks, kb, ldk, j0 + 32, a.Tk, a.d, w, 2, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 v = lds2(Vs + lo.brow[r & 3] + 8 * (r >> 2) * DP + bsel);
+            O[0] = MFMA(P[r], v.x, O[0]);
+            O[1] = MFMA(P[r], v.y, O[1]);
+        }
+    }
+    const float inv = 1.0f / l;
+    const int colw = 4 * l31 + bsel;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float ir = __shfl(inv, krow(r, half) + 32 * half, 64);
+        const int row = q0 + krow(r, half);
+        if (row < a.Tq && colw < a.d)
+            *reinterpret_cast<float2*>(a.out + ((int64_t)n * a.Tq + row) * a.ldo + col0 + colw) = make_float2(O[0][r] * ir, O[1][r] * ir);
+    }
+    if (w == 0 && qvalid && half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
+}
+
 // delta[n,h,q] = sum_c dctx[n,q,h*d+c] * ctx[n,q,h*d+c]
 // LG lanes (a power of two >= d/4) share one (row, head) segment: every lane moves one 16-byte piece of ctx and dctx, so a wave
 // sweeps 1 KiB of each row contiguously; the segment sum is a log2(LG)-step shuffle reduction (fixed order -> deterministic).
@@ -467,11 +630,25 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     Tile<DP>::issue(Vs, vb, ldv, 0, a.Tk, a.d, wave, nw, lane);      // V(0) travels while the register fragments are fetched
 
     float Qr[DP / 2], Gr[DP / 2];
-    load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     load_rowfrag<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
+    float dl;
+    if (a.delta_out) {
+        // delta = sum_c dO[q][c] * O[q][c] for this lane's query: each half-wave holds half of the head dimension (same association as
+        // attn_delta_kernel is not required -- delta is consumed through the same value by both backward kernels)
+        float Cr[DP / 2];          // the O fragment: dead before the accumulators come alive; all three fragments' loads fly together
+        load_rowfrag<DP>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        float acc = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < DP / 2; s4 += 4) acc += (Cr[s4] * Gr[s4] + Cr[s4 + 1] * Gr[s4 + 1]) + (Cr[s4 + 2] * Gr[s4 + 2] + Cr[s4 + 3] * Gr[s4 + 3]);
+        dl = acc + __shfl_xor(acc, 32, 64);
+        if (active && qvalid && half == 0) a.delta_out[sidx] = dl;
+    } else {
+        dl = qvalid ? a.delta[sidx] : 0.f;
+        load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+    }
     const float lse = qvalid ? a.lse[sidx] : INFINITY;          // a query past the end: p = exp(-inf) = 0
-    const float dl = qvalid ? a.delta[sidx] : 0.f;
     for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
 
     f32x16 dQ[NJ];
@@ -703,16 +880,18 @@ static int pick_waves(int T, int d) {
     return best;
 }
 // Pairs of waves per workgroup of the dK/dV kernel (32 keys per pair) and the number of Q/dO tile stages.
-static int pick_pairs(int T, int d) {
+static int pick_pairs(int T, int d, int bf16) {
     static const int force = env_int("YTVLN_ATTN_PAIRS", 0);
     if (force >= 1 && force <= 2) return force;
     const int tiles = (int)cdiv(T, 32);
     if (tiles == 1) return 1;
+    if (bf16) return 2;          // (the one-stage bf16 instantiation at d = 128 spills 200+ registers: two pairs, two stages)
     return d > 64 ? 1 : 2;
 }
-static int pick_stages(int d, int npairs) {
+static int pick_stages(int d, int npairs, int bf16) {
     static const int force = env_int("YTVLN_ATTN_DKV_STAGES", 0);
     if (force >= 1 && force <= 2) return force;
+    if (bf16) return 2;
     return (d > 64 && npairs == 1) ? 1 : 2;
 }
 
@@ -810,10 +989,14 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
     b.nb0 = b.gx0 * a0.heads * a0.N;
     const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
     YT_REQUIRE(total < (1ll << 31), "attn_fwd: grid too large");
+    static const int dsplit_on = env_int("YTVLN_ATTN_DSPLIT", 1);
+    const bool dsplit = dsplit_on && dp == 128 && nw == 2 && !a0.bf16;
+    for (int i = 0; i < np; ++i) b.p[i].dsplit = dsplit;
+    const size_t lds_bytes = lds_fwd(dp, maxTk) + (dsplit ? 4096 : 0);
 #ifdef YTVLN_ATTN_PROBES
     static const int probe = env_int("YTVLN_ATTN_PROBE", 0);
     if (probe && dp == 128 && drop && !a0.bf16) {
-#define YT_PROBE(P) case P: hipLaunchKernelGGL((attn_fwd_probe_kernel<P>), dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b); break
+#define YT_PROBE(P) case P: hipLaunchKernelGGL((attn_fwd_probe_kernel<P>), dim3((unsigned)total), dim3(64 * nw), lds_bytes, s, b); break
         switch (probe) {
             YT_PROBE(1); YT_PROBE(2); YT_PROBE(3); YT_PROBE(4); YT_PROBE(7); YT_PROBE(8); YT_PROBE(16); YT_PROBE(24); YT_PROBE(32); YT_PROBE(35);
             YT_PROBE(39); YT_PROBE(31);
@@ -824,7 +1007,7 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
         return 0;
     }
 #endif
-    YT_DISPATCH(attn_fwd_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
+    YT_DISPATCH(attn_fwd_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_bytes, s, b);
     YT_LAUNCH_CHECK("attn_fwd");
     return 0;
 }
@@ -843,7 +1026,13 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         drop = drop || a.p_drop > 0.f;
         maxTq = std::max(maxTq, a.Tq); maxTk = std::max(maxTk, a.Tk);
     }
-    for (int i = 0; i < np; ++i) launch_delta(b.p[i].ctx, b.p[i].dctx, b.p[i].ldo, const_cast<float*>(b.p[i].delta), a0.N, a0.heads, b.p[i].Tq, a0.d, s);
+    // delta[n,h,q] = sum_c dctx.ctx is produced by the dQ kernel's prologue (it owns the query rows) and read by the dK/dV kernel that
+    // follows it on the stream; YTVLN_ATTN_DELTA_KERNEL=1 restores the separate pass
+    static const int delta_kernel = env_int("YTVLN_ATTN_DELTA_KERNEL", 0);
+    for (int i = 0; i < np; ++i) {
+        if (delta_kernel) launch_delta(b.p[i].ctx, b.p[i].dctx, b.p[i].ldo, const_cast<float*>(b.p[i].delta), a0.N, a0.heads, b.p[i].Tq, a0.d, s);
+        b.p[i].delta_out = delta_kernel ? nullptr : const_cast<float*>(b.p[i].delta);
+    }
     {
         const int nw = pick_waves(maxTq, a0.d);
         b.gx0 = (int)cdiv(b.p[0].Tq, 32 * nw);
@@ -854,7 +1043,7 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
     }
     {
-        const int npairs = pick_pairs(maxTk, a0.d), stages = pick_stages(a0.d, npairs);
+        const int npairs = pick_pairs(maxTk, a0.d, a0.bf16), stages = pick_stages(a0.d, npairs, a0.bf16);
         b.gx0 = (int)cdiv(b.p[0].Tk, 32 * npairs);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32 * npairs) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
