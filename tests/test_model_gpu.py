@@ -932,3 +932,59 @@ def test_fp32x3_multimodal_pretraining_golden(dev, lib):
         test_g3_multimodal_pretraining(dev, lib)
     finally:
         ops.set_matmul_precision("fp32")
+
+
+def _bert_model(dev, seed, **over):
+    from ytvln import synth
+    from ytvln.vilbert import BertConfig, BertModel
+    m = BertModel(BertConfig(**cfg_dict("tiny_2_2_1.json", **{**ZERO_DROP, **over})))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(shapes, seed).items()})
+    return m.to(dev).train()
+
+
+def _check_bert(m, inputs, g, tag):
+    seq_t, seq_v, pool_t, pool_v, _ = m(*inputs)
+    loss = (pool_t * pool_v).sum() + 0.01 * seq_t.sum() + 0.01 * seq_v.sum()
+    loss.backward()
+    for name, t in (("seq_t", seq_t), ("seq_v", seq_v), ("pool_t", pool_t), ("pool_v", pool_v)):
+        close(t, g[f"{tag}/{name}"], 1e-4, 1e-4, f"{tag}/{name}")
+    close(loss, g[tag + "/loss"], 2e-3, 1e-5, tag + "/loss")
+    pd = dict(m.named_parameters())
+    assert {n for n, p in pd.items() if p.grad is not None} == set(g[tag + "/grad_names"].tolist())
+    for n, ref in zip(g[tag + "/grad_names"].tolist(), g[tag + "/grad_norms"]):
+        got = float(pd[n].grad.double().norm())
+        assert abs(got - ref) <= 2e-4 * ref + 1e-5, (tag, n, got, float(ref))
+
+
+def test_g13_in_batch_pairs_fast_mode_and_predict_feature(dev, lib):
+    """The three switches that are off in every target config (vilbert.py:771-782, 1391, 1430-1434) against the reference's own outputs
+    (oracle/gen_golden_branches.py): in_batch_pairs (3 texts x 3 images -> 9 rows), fast_mode (1 text against 4 images) and the
+    predict_feature MSE loss -- outputs, the loss and every gradient norm."""
+    from ytvln import synth
+    from ytvln.vilbert import BertConfig, BertForMultiModalPreTraining
+    g = gold("g13_branches.npz")
+
+    def inputs(nb):
+        b = synth.to_torch(nb, dev)
+        return b[6][:, 0], b[1][:, 0], b[2][:, 0], b[10][:, 0], b[7][:, 0], b[3][:, 0]
+
+    _check_bert(_bert_model(dev, 21, in_batch_pairs=True), inputs(synth.make_batch(bs=3, K=1, T=12, frames=2, boxes=5, seed=51)), g, "pairs")
+    ids, feat, loc, seg, tmask, vmask = inputs(synth.make_batch(bs=4, K=1, T=12, frames=2, boxes=5, seed=52))
+    _check_bert(_bert_model(dev, 22, fast_mode=True), (ids[:1], feat, loc, seg[:1], tmask[:1], vmask), g, "fast")
+
+    cfg = BertConfig(**cfg_dict("tiny_2_2_1.json", **ZERO_DROP, predict_feature=True))
+    m = BertForMultiModalPreTraining(cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(shapes, 23).items()})
+    m.to(dev).train()
+    b = synth.to_torch(synth.make_batch(bs=3, K=1, T=12, frames=2, boxes=5, seed=53), dev)
+    l = m(b[6][:, 0], b[1][:, 0], b[2][:, 0], None, b[7][:, 0], b[3][:, 0], b[8][:, 0], b[5][:, 0, 1:],
+          torch.from_numpy(g["mse/img_target"]).to(dev), torch.from_numpy(g["mse/nsl"]).to(dev))
+    (l[0] + l[1] + l[2]).sum().backward()
+    for got, ref in zip(l, g["mse/losses"]):
+        assert abs(float(got) - float(ref)) <= LOSS_TOL, (float(got), float(ref))
+    pd = dict(m.named_parameters())
+    assert {n for n, p in pd.items() if p.grad is not None} == set(g["mse/grad_names"].tolist())
+    for n, ref in zip(g["mse/grad_names"].tolist(), g["mse/grad_norms"]):
+        assert abs(float(pd[n].grad.double().norm()) - ref) <= 2e-4 * ref + 1e-5, n

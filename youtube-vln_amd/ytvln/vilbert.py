@@ -483,8 +483,6 @@ class BertEncoder(nn.Module):
                 output_all_encoded_layers=True, output_all_attention_masks=False):
         """Interleaving schedule of vilbert.py:737-811: for each (v_id, t_id) pair run the pending image layers, the
         pending text layers, then co-attention layer `count`; finally the remaining layers of both streams."""
-        if self.in_batch_pairs or self.FAST_MODE:
-            raise NotImplementedError("in_batch_pairs / fast_mode are off in every target config and not implemented on the HIP path")
         self._set_probs(bool(output_all_attention_masks))
         v_start = t_start = 0
         all_t, all_v, att_t, att_v, att_c = [], [], [], [], []
@@ -504,6 +502,20 @@ class BertEncoder(nn.Module):
             assert self.fixed_t_layer <= t_end and self.fixed_v_layer <= v_end
             image_embedding = run(self.v_layer, v_start, v_end, image_embedding, image_attention_mask, att_v, self.fixed_v_layer)
             txt_embedding = run(self.layer, t_start, t_end, txt_embedding, txt_attention_mask, att_t, self.fixed_t_layer)
+            if count == 0 and self.in_batch_pairs:
+                # every text of the batch against every image of the batch: B -> B^2 rows (vilbert.py:771-778); row (i, j) = text i, image j
+                b, r_, hv = image_embedding.shape
+                t_, ht = txt_embedding.shape[1], txt_embedding.shape[2]
+                image_embedding = image_embedding.unsqueeze(0).expand(b, b, r_, hv).contiguous().view(b * b, r_, hv)
+                image_attention_mask = image_attention_mask.reshape(b, -1).unsqueeze(0).expand(b, b, r_).contiguous().view(b * b, 1, 1, r_)
+                txt_embedding = txt_embedding.unsqueeze(1).expand(b, b, t_, ht).contiguous().view(b * b, t_, ht)
+                txt_attention_mask = txt_attention_mask.reshape(b, -1).unsqueeze(1).expand(b, b, t_).contiguous().view(b * b, 1, 1, t_)
+            if count == 0 and self.FAST_MODE:
+                # one text against many images (vilbert.py:780-782): the text rows are broadcast to the image batch
+                nb = image_embedding.size(0)
+                txt_embedding = txt_embedding.expand(nb, txt_embedding.size(1), txt_embedding.size(2)).contiguous()
+                txt_attention_mask = txt_attention_mask.reshape(txt_attention_mask.shape[0], -1).expand(nb, txt_embedding.size(1)).contiguous().view(
+                    nb, 1, 1, txt_embedding.size(1))
             if self.with_coattention:
                 image_embedding, txt_embedding, co_probs = self.c_layer[count](
                     image_embedding, image_attention_mask, txt_embedding, txt_attention_mask, co_attention_mask, False)
@@ -767,8 +779,6 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
         self.apply(self.init_bert_weights)
         self.predict_feature = config.predict_feature
-        if self.predict_feature:
-            raise NotImplementedError("predict_feature=True (MSE feature regression) is not on the accelerated path")
         print("model's option for predict_feature is ", config.predict_feature)
 
     def forward(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None,
@@ -783,9 +793,16 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
             n, r, c = prediction_scores_v.shape
             pv = prediction_scores_v[:, 1:].reshape(n * (r - 1), c)                      # region 0 dropped (:1429)
             label = (image_label == 1).reshape(-1)
-            # sum(KL * mask) / max(sum(mask), 0): the reference divides by zero when nothing is masked (:1440-1442);
-            # the fused kernel clamps the denominator at 1 in that degenerate case.
-            masked_img_loss = ops.kl_masked(pv, image_target.reshape(n * (r - 1), c).float(), label)
+            if self.predict_feature:
+                # MSE feature regression (:1391, 1430-1434): sum((pred - target)^2 over masked regions) / max(#masked * C, 1).  Off in every
+                # target config: a handful of elementwise torch kernels on the device, no fused kernel of its own.
+                lm = label.to(pv.dtype).unsqueeze(1)
+                diff = pv - image_target.reshape(n * (r - 1), c).to(pv.dtype)
+                masked_img_loss = (diff * diff * lm).sum() / torch.clamp(lm.sum() * c, min=1.0)
+            else:
+                # sum(KL * mask) / max(sum(mask), 0): the reference divides by zero when nothing is masked (:1440-1442);
+                # the fused kernel clamps the denominator at 1 in that degenerate case.
+                masked_img_loss = ops.kl_masked(pv, image_target.reshape(n * (r - 1), c).float(), label)
             masked_lm_loss = ops.cross_entropy(prediction_scores_t.view(-1, self.config.vocab_size), masked_lm_labels.view(-1), -1)
             next_sentence_loss = ops.cross_entropy(seq_relationship_score.view(-1, 2), next_sentence_label.view(-1), -1)
             return masked_lm_loss.unsqueeze(0), masked_img_loss.unsqueeze(0), next_sentence_loss.unsqueeze(0)
