@@ -62,7 +62,7 @@ def main():
     m = R.vilbert.BertForMultiModalPreTraining(rcfg)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(shapes, 23).items()})
-    m.train()
+    m.eval()          # (BertPreTrainingHeads carries a hard-wired Dropout(0.1) in front of the NSP head: eval mode keeps torch's RNG out of the fixture)
     nb3 = synth.make_batch(bs=3, K=1, T=12, frames=2, boxes=5, seed=53)
     b = synth.to_torch(nb3)
     ids, feat, loc, vmask = b[6][:, 0], b[1][:, 0], b[2][:, 0], b[3][:, 0]

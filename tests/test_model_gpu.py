@@ -977,7 +977,7 @@ def test_g13_in_batch_pairs_fast_mode_and_predict_feature(dev, lib):
     m = BertForMultiModalPreTraining(cfg)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(shapes, 23).items()})
-    m.to(dev).train()
+    m.to(dev).eval()          # eval like the fixture (the NSP head's hard-wired Dropout(0.1) would bring torch's RNG in)
     b = synth.to_torch(synth.make_batch(bs=3, K=1, T=12, frames=2, boxes=5, seed=53), dev)
     l = m(b[6][:, 0], b[1][:, 0], b[2][:, 0], None, b[7][:, 0], b[3][:, 0], b[8][:, 0], b[5][:, 0, 1:],
           torch.from_numpy(g["mse/img_target"]).to(dev), torch.from_numpy(g["mse/nsl"]).to(dev))

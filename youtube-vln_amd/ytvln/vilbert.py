@@ -751,10 +751,11 @@ class BertModel(BertPreTrainedModel):
             ext_t = torch.zeros((n, 1, 1, t), dtype=torch.float32, device=input_txt.device)
         else:
             ext_t = ((1.0 - attention_mask.to(torch.float32)) * -10000.0).view(n, 1, 1, t)
+        nv = input_imgs.size(0)          # (differs from the text batch only in fast_mode: one text against many images)
         if image_attention_mask is None:
-            ext_v = torch.zeros((n, 1, 1, r), dtype=torch.float32, device=input_txt.device)
+            ext_v = torch.zeros((nv, 1, 1, r), dtype=torch.float32, device=input_txt.device)
         else:
-            ext_v = ((1.0 - image_attention_mask.to(torch.float32)) * -10000.0).view(n, 1, 1, r)
+            ext_v = ((1.0 - image_attention_mask.to(torch.float32)) * -10000.0).view(nv, 1, 1, r)
         # co_attention_mask only feeds the dead use_co_attention_mask branch (vilbert.py:736): not materialised.
 
         embedding_output = self.embeddings(input_txt, token_type_ids)
