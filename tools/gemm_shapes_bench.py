@@ -1,0 +1,36 @@
+"""Per-shape GEMM rates at the cfg-2 shapes (HIP events, 20 launches each).  Planner knobs are process-wide environment variables
+(YTVLN_GEMM_BIG_TA, YTVLN_GEMM_TILE, YTVLN_GEMM_SPLITS ...): run once per setting.  SHAPES=wgrad|dx|fwd|all."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd"))
+import torch
+from ytvln import ops
+dev = torch.device("cuda", 0)
+SETS = {
+    "wgrad": [(1024, 1024, 16128, 1, 0), (3072, 1024, 16128, 1, 0), (2048, 1024, 16128, 1, 0), (768, 3072, 4480, 1, 0), (3072, 768, 4480, 1, 0),
+              (2304, 768, 4480, 1, 0), (768, 768, 4480, 1, 0), (30522, 768, 4480, 1, 0)],
+    "dx": [(16128, 1024, 1024, 0, 0), (16128, 1024, 3072, 0, 0), (4480, 768, 3072, 0, 0), (4480, 3072, 768, 0, 0), (4480, 768, 2304, 0, 0),
+           (4480, 768, 768, 0, 0)],
+    "fwd": [(16128, 1024, 1024, 0, 1), (16128, 3072, 1024, 0, 1), (4480, 768, 3072, 0, 1), (4480, 3072, 768, 0, 1)],
+}
+which = os.environ.get("SHAPES", "all")
+shapes = sum(SETS.values(), []) if which == "all" else SETS[which]
+
+
+def run(M, N, K, ta, tb, iters=20):
+    A = torch.randn((K, M) if ta else (M, K), device=dev)
+    B = torch.randn((N, K) if tb else (K, N), device=dev)
+    C = torch.empty(M, N, device=dev)
+    lda = M if ta else K; ldb = K if tb else N
+    for _ in range(3): ops._gemm(A, lda, ta, B, ldb, tb, C, N, M, N, K)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): ops._gemm(A, lda, ta, B, ldb, tb, C, N, M, N, K)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms * 1000, 2.0 * M * N * K / ms / 1e9
+
+
+for s in shapes:
+    us, tf = run(*s)
+    print(f"{s[0]:6d} {s[1]:6d} {s[2]:6d} tA{s[3]} tB{s[4]}  {us:8.1f} us  {tf:6.1f} TF/s", flush=True)

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libytvln.so")
+# YTVLN_LIB: an alternative build of the SAME ABI (A/B experiments: tools/, scratch/); a missing file still fails loudly in load()
+LIB_PATH = os.path.abspath(os.environ["YTVLN_LIB"]) if os.environ.get("YTVLN_LIB") else os.path.join(HERE, "lib", "libytvln.so")
 
 
 class YtvlnLibraryError(RuntimeError):
