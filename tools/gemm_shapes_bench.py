@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from ytvln import ops
 dev = torch.device("cuda", 0)
+if os.environ.get("PRECISION"):
+    ops.set_matmul_precision(os.environ["PRECISION"])      # fp32x3 | bf16
 SETS = {
     "wgrad": [(1024, 1024, 16128, 1, 0), (3072, 1024, 16128, 1, 0), (2048, 1024, 16128, 1, 0), (768, 3072, 4480, 1, 0), (3072, 768, 4480, 1, 0),
               (2304, 768, 4480, 1, 0), (768, 768, 4480, 1, 0), (30522, 768, 4480, 1, 0)],

@@ -38,6 +38,7 @@ struct GemmArgs {
     int x3;               // 1: fp32 operands split into three bf16 terms in registers, six bf16 MFMAs per product (YTVLN_GEMM_SPLIT_BF16X3)
     float* asum;          // optional: asum[m] = sum_k op(A)[m, k] (bias gradient riding on the weight-gradient GEMM); M-contiguous A, LDS-DMA path only
     float* asum_ws;       // split-K: per-split partial row sums [splits][M], reduced in a fixed order by splitk_reduce_kernel
+    int split_map;        // 1: split-K workgroups are laid out split-major per XCD (see decode_tile)
 };
 
 constexpr int BK = 32;
@@ -62,10 +63,16 @@ __device__ __forceinline__ TileCoord tile_coord(int t, int tiles_m, int tiles_n)
     c.n = r / rows;
     return c;
 }
-__device__ __forceinline__ TileCoord decode_tile(int bid, int tiles_m, int tiles_n, int splits) {
+__device__ __forceinline__ TileCoord decode_tile(int bid, int tiles_m, int tiles_n, int splits, int split_major = 1) {
+    // Workgroups that read the same operand panels must meet in one XCD's L2 at about the same time.  Without split-K an XCD gets a
+    // contiguous run of the (group-major) tile order; with split-K it gets a contiguous run of the split-major (split, tile) order, i.e.
+    // neighbouring tiles of ONE k range (they share its A / B panels) -- not, as before round 2, all splits of one tile scattered over the
+    // XCDs by bid % 8 (L2 hit rate 0.31 -> see profiles/round2_gemm_traffic.json; YTVLN_GEMM_SPLIT_MAP=0 restores that order).
     int t, split;
-    if (splits > 1) { split = bid % splits; t = bid / splits; }
-    else { split = 0; t = xcd_remap(bid, tiles_m * tiles_n); }
+    const int ntiles = tiles_m * tiles_n;
+    if (splits > 1 && split_major) { const int id = xcd_remap(bid, ntiles * splits); split = id / ntiles; t = id - split * ntiles; }
+    else if (splits > 1) { split = bid % splits; t = bid / splits; }
+    else { split = 0; t = xcd_remap(bid, ntiles); }
     TileCoord c = tile_coord(t, tiles_m, tiles_n);
     c.split = split;
     return c;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
-    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits);
+    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits, g.split_map);
     const int m0 = tc.m * BM, n0 = tc.n * BN;
 
     f32x16 acc[TM][TN];
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave >> 1) * (BM / WM), wn0 = (wave & 1) * (BN / 2);
-    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits);
+    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits, g.split_map);
     const int m0 = tc.m * BM, n0 = tc.n * BN;
     const int kbeg = tc.split * g.kchunk;
     const int kend = min(g.Kloop, kbeg + g.kchunk);
@@ -1088,6 +1095,8 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     hipStream_t s = as_stream(stream);
     g.splits = 1; g.kchunk = K; g.ws = nullptr; g.sk_flags = nullptr;
     g.x3 = (flags & YTVLN_GEMM_SPLIT_BF16X3) != 0;
+    static const int split_map = getenv("YTVLN_GEMM_SPLIT_MAP") ? atoi(getenv("YTVLN_GEMM_SPLIT_MAP")) : 1;
+    g.split_map = split_map;
     g.asum = nullptr; g.asum_ws = nullptr;
     // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
     // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
@@ -1224,7 +1233,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
     g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr; g.x3 = 0;
-    g.asum = nullptr; g.asum_ws = nullptr;
+    g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
     const int want = plan_splits_bf16(M, N, K / 2, epilogue);
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
