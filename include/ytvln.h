@@ -116,6 +116,11 @@ int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpo
  * the input-gradient GEMM in the first form and of the weight-gradient GEMM in the second */
 int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain, uint16_t* out_t, int64_t ld_t,
                          void* stream);
+/* the same staging, also leaving colsum_part[b][c] = sum over the 64 rows of row block b of x[.][c]  (b < ceil(rows/64), c < cols; fixed
+ * summation order): first stage of the bias gradient db = colsum(dY) in bf16 mode, finished by ytvln_colsum_f32 over the partials
+ * (the reference's bias gradient is autograd's sum over rows of dY, torch.nn.Linear as used in vilbert/vilbert.py:266-268 etc.) */
+int ytvln_cast_bf16_dual_colsum(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain, uint16_t* out_t,
+                                int64_t ld_t, float* colsum_part, void* stream);
 int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                        float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
                        int64_t workspace_elems, void* stream);

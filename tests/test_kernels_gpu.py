@@ -822,12 +822,34 @@ def test_cast_bf16_dual_equals_separate_stagings(dev, lib, rows, cols):
     """One pass producing both bf16 stagings == the plain and the transposing staging kernels, bit for bit (zero tails included)."""
     from ytvln import ops
     x = torch.randn(rows, cols + 8, device=dev)[:, :cols]                    # a strided view: leading dimension cols + 8
-    (p, ldp), (t, ldt) = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
+    (p, ldp), (t, ldt), _ = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
     p2, ldp2 = ops._stage_bf16(x, x.stride(0), rows, cols, False)
     t2, ldt2 = ops._stage_bf16(x, x.stride(0), rows, cols, True)
     assert (ldp, ldt) == (ldp2, ldt2)
     assert torch.equal(p.view(torch.int16), p2.view(torch.int16)) and torch.equal(t.view(torch.int16), t2.view(torch.int16))
     assert torch.equal(p[:, :cols].float(), x.bfloat16().float()) and bool((p[:, cols:] == 0).all()) and bool((t[:, rows:] == 0).all())
+
+
+@pytest.mark.parametrize("rows,cols", [(256, 128), (300, 200), (65, 1601), (4480, 768), (70, 30), (16128, 1024)])
+def test_cast_bf16_dual_colsum_rides_on_the_staging(dev, lib, rows, cols):
+    """bf16 mode's bias gradient: the staging pass that reads dY also leaves per-64-row column sums; finished by colsum they equal the
+    fp64 column sums to fp32 rounding, the stagings are bit-identical to the plain dual pass, and two runs agree bit for bit."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = (torch.randn(rows, cols + 8, generator=g) * 3 + 0.5).to(dev)[:, :cols]
+    (p0, _), (t0, _), done0 = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
+    assert done0 is False
+    outs = []
+    for _ in range(2):
+        db = torch.full((cols,), float("nan"), device=dev)
+        (p, ldp), (t, ldt), done = ops._stage_bf16_dual(x, x.stride(0), rows, cols, colsum_out=db)
+        assert done is True
+        assert torch.equal(p.view(torch.int16), p0.view(torch.int16)) and torch.equal(t.view(torch.int16), t0.view(torch.int16))
+        outs.append(db)
+    assert torch.equal(outs[0], outs[1])
+    ref = x.double().sum(0)
+    scale = x.double().abs().sum(0)
+    assert bool(((outs[0].double() - ref).abs() <= 4e-7 * scale + 1e-30).all()), float(((outs[0].double() - ref).abs() / scale).max())
 
 
 def test_scatter_add_rows_sorted_is_exact_and_reproducible(dev, lib):

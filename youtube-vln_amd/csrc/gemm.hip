@@ -983,9 +983,12 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
 
 // Both stagings of one fp32 matrix in a single pass (a gradient dY feeds the input-gradient GEMM as [rows][cols] and the
 // weight-gradient GEMM as [cols][rows]): x is read once, 64 x 64 tiles through LDS as in cast_bf16_t_kernel.
+// COLSUM: the block also leaves the column sums of its 64 rows in part[blockRow][c] (fixed summation order: 16-row quarters, then the
+// four quarters) -- the first stage of the bias gradient db = colsum(dY), riding on the pass that reads dY anyway.
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void cast_bf16_dual_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols,
                                                              uint16_t* __restrict__ outp, int64_t ldp, uint16_t* __restrict__ outt, int64_t ldt,
-                                                             int vec) {
+                                                             int vec, float* __restrict__ part) {
     __shared__ float tile[64][65];
     const int tiles_c = (int)(ldp >> 6);
     const int r0 = (blockIdx.x / tiles_c) << 6, c0 = (blockIdx.x % tiles_c) << 6;
@@ -1018,6 +1021,17 @@ __global__ __launch_bounds__(256) void cast_bf16_dual_kernel(const float* __rest
                                  bf16_pack(tile[r + 4][c], tile[r + 5][c]), bf16_pack(tile[r + 6][c], tile[r + 7][c]));
             *reinterpret_cast<uint4*>(outt + (int64_t)(c0 + c) * ldt + r0 + r) = o;
         }
+    }
+    if constexpr (COLSUM) {
+        __shared__ float quarter[4][64];
+        const int c = tid & 63, q = tid >> 6;
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += tile[16 * q + r][c];          // rows past `rows` were staged as zeros
+        quarter[q][c] = acc;
+        __syncthreads();
+        if (tid < 64 && c0 + tid < cols)
+            part[(int64_t)(blockIdx.x / tiles_c) * cols + c0 + tid] = (quarter[0][tid] + quarter[1][tid]) + (quarter[2][tid] + quarter[3][tid]);
     }
 }
 
@@ -1203,19 +1217,36 @@ extern "C" int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, 
     return 0;
 }
 
-extern "C" int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
-                                    uint16_t* out_t, int64_t ld_t, void* stream) {
-    YT_REQUIRE(x && out_plain && out_t && rows > 0 && cols > 0 && ldx >= cols, "cast_bf16_dual: bad argument");
+static int cast_bf16_dual_impl(const char* name, const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
+                               uint16_t* out_t, int64_t ld_t, float* colsum_part, void* stream) {
+    YT_REQUIRE(x && out_plain && out_t && rows > 0 && cols > 0 && ldx >= cols, "%s: bad argument", name);
     YT_REQUIRE(ld_plain % 64 == 0 && ld_plain >= cols && ld_plain < cols + 64 && ld_t % 64 == 0 && ld_t >= rows && ld_t < rows + 64,
-               "cast_bf16_dual: leading dimensions must be the contraction lengths rounded up to 64");
-    YT_REQUIRE(((reinterpret_cast<uintptr_t>(out_plain) | reinterpret_cast<uintptr_t>(out_t)) & 15) == 0, "cast_bf16_dual: outputs must be 16-byte aligned");
+               "%s: leading dimensions must be the contraction lengths rounded up to 64", name);
+    YT_REQUIRE(((reinterpret_cast<uintptr_t>(out_plain) | reinterpret_cast<uintptr_t>(out_t)) & 15) == 0, "%s: outputs must be 16-byte aligned", name);
     const int vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
     const int64_t tiles = (ld_t / 64) * (ld_plain / 64);
-    YT_REQUIRE(tiles < (1ll << 31), "cast_bf16_dual: matrix too large");
-    hipLaunchKernelGGL(cast_bf16_dual_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, out_plain, ld_plain,
-                       out_t, ld_t, vec);
-    YT_LAUNCH_CHECK("cast_bf16_dual");
+    YT_REQUIRE(tiles < (1ll << 31), "%s: matrix too large", name);
+    if (colsum_part)
+        hipLaunchKernelGGL(cast_bf16_dual_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, out_plain,
+                           ld_plain, out_t, ld_t, vec, colsum_part);
+    else
+        hipLaunchKernelGGL(cast_bf16_dual_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, out_plain,
+                           ld_plain, out_t, ld_t, vec, (float*)nullptr);
+    YT_LAUNCH_CHECK(name);
     return 0;
+}
+
+extern "C" int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
+                                    uint16_t* out_t, int64_t ld_t, void* stream) {
+    return cast_bf16_dual_impl("cast_bf16_dual", x, ldx, rows, cols, out_plain, ld_plain, out_t, ld_t, nullptr, stream);
+}
+
+// Same staging, plus colsum_part[b][c] = sum of x[r][c] over the 64 rows r of row block b (b < ceil(rows / 64), c < cols): the first stage
+// of a deterministic column sum (finish with ytvln_colsum_f32 over the [ceil(rows/64)][cols] partials).
+extern "C" int ytvln_cast_bf16_dual_colsum(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
+                                           uint16_t* out_t, int64_t ld_t, float* colsum_part, void* stream) {
+    YT_REQUIRE(colsum_part != nullptr, "cast_bf16_dual_colsum: NULL partial buffer");
+    return cast_bf16_dual_impl("cast_bf16_dual_colsum", x, ldx, rows, cols, out_plain, ld_plain, out_t, ld_t, colsum_part, stream);
 }
 
 extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,

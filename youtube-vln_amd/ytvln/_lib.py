@@ -49,6 +49,7 @@ SIGNATURES = {
     "ytvln_gemm_plan": [I32, I32, I32, I32, I32, P, P, P],
     "ytvln_gemm_plan_x3": [I32, I32, I32, I32, I32, P, P, P],
     "ytvln_cast_bf16_dual": [P, I64, I32, I32, P, I64, P, I64, P],
+    "ytvln_cast_bf16_dual_colsum": [P, I64, I32, I32, P, I64, P, I64, P, P],
     "ytvln_cast_bf16": [P, I64, I32, I32, I32, P, I64, P],
     "ytvln_gemm_bf16_nt": [P, I64, P, I64, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, P],
     "ytvln_ln_fwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],

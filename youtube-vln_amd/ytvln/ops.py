@@ -147,13 +147,21 @@ def _stage_bf16(X: Tensor, ld: int, rows: int, cols: int, transpose: bool) -> Tu
     return out, ldo
 
 
-def _stage_bf16_dual(X: Tensor, ld: int, rows: int, cols: int):
-    """Both bf16 stagings of the fp32 matrix X [rows, cols] from ONE read: ([rows][cols->64], ld) and ([cols][rows->64], ld)."""
+def _stage_bf16_dual(X: Tensor, ld: int, rows: int, cols: int, colsum_out: Optional[Tensor] = None):
+    """Both bf16 stagings of the fp32 matrix X [rows, cols] from ONE read: ([rows][cols->64], ld) and ([cols][rows->64], ld).
+    `colsum_out` = a [cols] tensor that receives the column sums of X (a bias gradient when X is dY): the staging pass leaves one partial
+    row per 64 rows, a small `colsum` over those finishes it -- instead of a second full read of X."""
     ldp, ldt = (cols + 63) // 64 * 64, (rows + 63) // 64 * 64
     plain = torch.empty((rows, ldp), dtype=torch.bfloat16, device=X.device)
     trans = torch.empty((cols, ldt), dtype=torch.bfloat16, device=X.device)
+    if colsum_out is not None and _FUSED_BIAS_GRAD:
+        nblk = ldt // 64
+        part = torch.empty((nblk, cols), dtype=torch.float32, device=X.device)
+        call("ytvln_cast_bf16_dual_colsum", _ptr(X), ld, rows, cols, _ptr(plain), ldp, _ptr(trans), ldt, _ptr(part), _stream())
+        colsum(part, nblk, cols, cols, out=colsum_out)
+        return (plain, ldp), (trans, ldt), True
     call("ytvln_cast_bf16_dual", _ptr(X), ld, rows, cols, _ptr(plain), ldp, _ptr(trans), ldt, _stream())
-    return (plain, ldp), (trans, ldt)
+    return (plain, ldp), (trans, ldt), False
 
 
 _FWD_DUAL = os.environ.get("YTVLN_BF16_FWD_DUAL", "1") != "0"      # experiment knob: 0 -> re-stage the inputs in backward
@@ -410,7 +418,7 @@ class LinearFn(torch.autograd.Function):
         # the weight-gradient GEMM -- instead of a second fp32 pass over it in backward
         st_p = ctx.x_t = None
         if _FWD_DUAL and ctx.needs_input_grad[1] and _bf16_eligible(M, N, K) and _bf16_eligible(N, K, M):
-            st_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K)
+            st_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K)[:2]
         _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi, A_staged=st_p)
         ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
         ctx.in_shape = x.shape
@@ -437,8 +445,14 @@ class LinearFn(torch.autograd.Function):
             dy, ldy, flags, _ = _rows_of_grad(dy, M, N)
         dx = dw = db = None
         st_p = st_t = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_db:
+            db = _direct_grad(ctx.btargets, (N,))
+            if db is None:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+        db_done = False
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _bf16_eligible(M, K, N) and _bf16_eligible(N, K, M):
-            st_p, st_t = _stage_bf16_dual(dy, ldy, M, N)          # dY read once for both of its roles
+            st_p, st_t, db_done = _stage_bf16_dual(dy, ldy, M, N, colsum_out=db if want_db else None)   # dY read once for all its roles
         if ctx.needs_input_grad[0]:
             acc = _accumulate_target(dres, M, K)
             if acc is not None:          # dx = d(residual) + dY W, written over the residual branch's gradient
@@ -450,19 +464,14 @@ class LinearFn(torch.autograd.Function):
                 dx = dx.view(ctx.in_shape)
                 if dres is not None:
                     dx = dx + dres.reshape(ctx.in_shape)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if want_db:
-            db = _direct_grad(ctx.btargets, (N,))
-            if db is None:
-                db = torch.empty(N, dtype=torch.float32, device=dy.device)
-        db_done = False
         if ctx.needs_input_grad[1]:
             dw = _direct_grad(ctx.targets, (N, K))
             if dw is None:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            # db = column sums of dY = row sums of the A operand (dY^T) of this launch: rides on the GEMM when it can
+            # db = column sums of dY = row sums of the A operand (dY^T) of this launch: rides on the GEMM when it can (fp32 modes; in bf16
+            # mode it rode on the staging pass above)
             db_done = _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t, B_staged=ctx.x_t,
-                            rowsum=db if want_db else None)
+                            rowsum=db if (want_db and not db_done) else None) or db_done
             ctx.x_t = None
         if want_db and not db_done:
             colsum(dy, M, N, ldy, out=db)
@@ -493,11 +502,11 @@ class FFNFn(torch.autograd.Function):
         z = torch.empty_like(h) if need_grad else None
         # bf16 mode: x and h are each read once for both bf16 roles (this GEMM's [M][K] operand, the weight-gradient GEMM's [K][M])
         dual = _FWD_DUAL and need_grad and _bf16_eligible(M, I, K) and _bf16_eligible(I, K, M) and _bf16_eligible(M, N, I) and _bf16_eligible(N, I, M)
-        sx_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K) if dual else (None, None)
+        sx_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K)[:2] if dual else (None, None)
         _gemm(x2, lda, 0, w1, w1.stride(0), 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU, A_staged=sx_p)
         del sx_p
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        sh_p, ctx.h_t = _stage_bf16_dual(h, I, M, I) if dual else (None, None)
+        sh_p, ctx.h_t = _stage_bf16_dual(h, I, M, I)[:2] if dual else (None, None)
         _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2, A_staged=sh_p)
         ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
         ctx.targets = (_targets_of(w1), _targets_of(w2), _targets_of(b1), _targets_of(b2))
@@ -517,18 +526,22 @@ class FFNFn(torch.autograd.Function):
         dev = dy.device
         dz = torch.empty((M, I), dtype=torch.float32, device=dev)
         dual = _bf16_eligible(M, I, N) and _bf16_eligible(N, I, M) and _bf16_eligible(M, K, I) and _bf16_eligible(I, K, M)
-        sy_p, sy_t = _stage_bf16_dual(dy, N, M, N) if dual else (None, None)
+        db2 = _direct_grad(ctx.targets[3], (N,))
+        if db2 is None:
+            db2 = torch.empty(N, dtype=torch.float32, device=dev)
+        db1 = _direct_grad(ctx.targets[2], (I,))
+        if db1 is None:
+            db1 = torch.empty(I, dtype=torch.float32, device=dev)
+        sy_p, sy_t, db2_done = _stage_bf16_dual(dy, N, M, N, colsum_out=db2) if dual else (None, None, False)   # bf16: db2 rides on the staging
         _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU, A_staged=sy_p)   # dH * gelu'(z)
         dw2 = _direct_grad(ctx.targets[1], (N, I))
         if dw2 is None:
             dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
-        db2 = _direct_grad(ctx.targets[3], (N,))
-        if db2 is None:
-            db2 = torch.empty(N, dtype=torch.float32, device=dev)
-        if not _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t, B_staged=ctx.h_t, rowsum=db2):      # db2 rides on the dW2 GEMM
+        # fp32 modes: db2 rides on the dW2 GEMM
+        if not (_gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t, B_staged=ctx.h_t, rowsum=None if db2_done else db2) or db2_done):
             colsum(dy, M, N, N, out=db2)
         ctx.h_t = None
-        sz_p, sz_t = _stage_bf16_dual(dz, I, M, I) if dual else (None, None)
+        sz_p, sz_t, db1_done = _stage_bf16_dual(dz, I, M, I, colsum_out=db1) if dual else (None, None, False)
         dx = None
         if ctx.needs_input_grad[0]:
             acc = _accumulate_target(dres, M, K)
@@ -544,10 +557,7 @@ class FFNFn(torch.autograd.Function):
         dw1 = _direct_grad(ctx.targets[0], (I, K))
         if dw1 is None:
             dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
-        db1 = _direct_grad(ctx.targets[2], (I,))
-        if db1 is None:
-            db1 = torch.empty(I, dtype=torch.float32, device=dev)
-        if not _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t, B_staged=ctx.x_t, rowsum=db1):
+        if not (_gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t, B_staged=ctx.x_t, rowsum=None if db1_done else db1) or db1_done):
             colsum(dz, M, I, I, out=db1)
         ctx.x_t = None
         return dx, dw1, db1, dw2, db2, None
