@@ -289,21 +289,29 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 __global__ __launch_bounds__(256) void scatter_add_rows_sorted_kernel(const float* __restrict__ x, int64_t ldx,
                                                                       const int64_t* __restrict__ sorted_idx, const int64_t* __restrict__ perm,
                                                                       int M, int H, float* __restrict__ tg, int64_t skip) {
+    // Work unit = (head of a run, 64-lane column chunk): a long run ([MASK] fills ~12 % of the rows) is walked by H/256 waves side by
+    // side, eight row loads in flight at a time; the additions keep the order of the run, so the sums do not depend on the launch shape.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int H4 = H >> 2;
-    for (int i = blockIdx.x * 4 + wave; i < M; i += gridDim.x * 4) {
+    const int H4 = H >> 2, nchunk = (H4 + 63) >> 6;
+    const int64_t units = (int64_t)M * nchunk;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < units; u += (int64_t)gridDim.x * 4) {
+        const int i = (int)(u / nchunk), c = (int)(u % nchunk) * 64 + lane;
         const int64_t k = sorted_idx[i];
         if (k == skip || (i > 0 && sorted_idx[i - 1] == k)) continue;          // not the head of a run
-        for (int c0 = 0; c0 < H4; c0 += 64) {
-            const int c = c0 + lane;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < H4)
-                for (int j = i; j < M && sorted_idx[j] == k; ++j) acc = f4add(acc, reinterpret_cast<const float4*>(x + perm[j] * ldx)[c]);
-            if (c < H4) {
-                float4* dst = reinterpret_cast<float4*>(tg + k * (int64_t)H) + c;
-                *dst = f4add(*dst, acc);
-            }
+        if (c >= H4) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int j = i;
+        while (j + 7 < M && sorted_idx[j + 7] == k) {                             // (sorted: rows j .. j+7 all belong to the run)
+            float4 a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = reinterpret_cast<const float4*>(x + perm[j + q] * ldx)[c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = f4add(acc, a[q]);
+            j += 8;
         }
+        for (; j < M && sorted_idx[j] == k; ++j) acc = f4add(acc, reinterpret_cast<const float4*>(x + perm[j] * ldx)[c]);
+        float4* dst = reinterpret_cast<float4*>(tg + k * (int64_t)H) + c;
+        *dst = f4add(*dst, acc);
     }
 }
 
@@ -512,7 +520,7 @@ extern "C" int ytvln_scatter_add_rows_sorted_f32(const float* x, int64_t ldx, co
     YT_REQUIRE(x && sorted_idx && perm && table_grad && H > 0 && H % 4 == 0 && ldx % 4 == 0, "scatter_add_rows_sorted: bad argument (H, ldx multiples of 4)");
     YT_REQUIRE(al16(x) && al16(table_grad), "scatter_add_rows_sorted: pointers must be 16-byte aligned");
     if (M == 0) return 0;
-    hipLaunchKernelGGL(scatter_add_rows_sorted_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M, 4), 4096)), dim3(256), 0, as_stream(stream), x,
+    hipLaunchKernelGGL(scatter_add_rows_sorted_kernel, dim3((unsigned)std::min<int64_t>(cdiv((int64_t)M * cdiv(H / 4, 64), 4), 8192)), dim3(256), 0, as_stream(stream), x,
                        ldx, sorted_idx, perm, M, H, table_grad, skip_idx);
     YT_LAUNCH_CHECK("scatter_add_rows_sorted");
     return 0;
