@@ -313,8 +313,9 @@ def main():
                     return static["loss"], None
             else:
                 from ytvln.distributed import GraphedTrainStep
-                gs = GraphedTrainStep(runner, opt, lambda: utils_init.train_step(
-                    runner, opt, None, batch, args, 0, all_options=True, loss_aware_heads=a.loss_aware_heads, optimizer_step=False)[0])
+                gs = GraphedTrainStep(runner, opt, lambda backward=None: utils_init.train_step(
+                    runner, opt, None, batch, args, 0, all_options=True, loss_aware_heads=a.loss_aware_heads, optimizer_step=False,
+                    backward=backward)[0])
 
                 def graph_step(i):
                     return gs.step(sched), None
@@ -324,9 +325,11 @@ def main():
         ok = control_reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
         if ok:
             step = graph_step
+            how = (f"{len(gs.graphs) + 1} hipGraphs per step (forward + backward in {len(gs.graphs)} phases | AdamW), every phase's gradients all-reduced "
+                   f"on a communication stream under the next phases") if (dp_wrap and gs.mode == "phased") else \
+                "two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them"
             execution = "hipGraph replay of the captured step" if not dp_wrap else \
-                (f"two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them "
-                 f"[{gs.mode}; exchange: {'ytvln_rccl_* C ABI' if runner.comm is not None else 'torch.distributed ' + dist.get_backend()}]")
+                (f"{how} [{gs.mode}; exchange: {'ytvln_rccl_* C ABI' if runner.comm is not None else 'torch.distributed ' + dist.get_backend()}]")
         else:
             torch.cuda.synchronize()
             opt.zero_grad()

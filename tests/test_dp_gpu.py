@@ -66,9 +66,17 @@ def _worker(rank, world, port, q, mode="eager"):
             U.train_step(dp, opt, sched, batch, args, step, all_options=True)
     else:       # one eager step, then two replays of the two-graph step with the exchange between the graphs
         U.train_step(dp, opt, sched, batch, args, 0, all_options=True)
-        gs = D.GraphedTrainStep(dp, opt, lambda: U.train_step(dp, opt, None, batch, args, 0, all_options=True, optimizer_step=False)[0],
-                                bucket_bytes=64 << 10)
-        assert len(gs._slices) > 1
+        if mode == "phased":
+            os.environ["YTVLN_DP_CUTS"] = "t0,c0,v1"
+        gs = D.GraphedTrainStep(dp, opt, lambda backward=None: U.train_step(dp, opt, None, batch, args, 0, all_options=True, optimizer_step=False,
+                                                                            backward=backward)[0],
+                                bucket_bytes=64 << 10, mode="phased" if mode == "phased" else None)
+        assert len(gs._slices) > 1 and gs.mode == ("phased" if mode == "phased" else "split")
+        if mode == "phased":
+            # every parameter that receives a gradient travels in exactly one group (a parameter left out would make the replicas diverge
+            # and the comparison with the single-process average below fail)
+            owned = sum(hi - lo for g in gs._group_slices for lo, hi in g)
+            assert len(gs.graphs) == 4 and owned == sum(opt.arena_range(p)[1] for p in model.parameters() if opt.arena_range(p) is not None)
         for step in range(2):
             loss = gs.step(sched)
         assert torch.isfinite(loss).item()
@@ -84,7 +92,7 @@ def _worker(rank, world, port, q, mode="eager"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["eager", "graphed", "accum"])
+@pytest.mark.parametrize("mode", ["eager", "graphed", "phased", "accum"])
 def test_two_ranks_match_single_process_average(dev, lib, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -234,3 +234,37 @@ def test_checkpoint_interop_evidence_is_committed():
     assert rep["ok"] and rep["optimizer_steps_all_3"] and rep["start_epoch"] == 5
     assert rep["extra_keys_ignored_by_reference"] == ["ytvln_rng_state"]
     assert rep["max_abs_diff_vs_repo_step3"]["p"] < rep["tolerance"]["p"]
+
+
+def test_encoder_cut_points_split_the_backward_without_changing_gradients():
+    """BertEncoder._cut (the hook of ytvln.distributed's phased backward): detached leaves above the cut, the originals below; running
+    the backward in two phases through the recorded pair gives the gradients of the uncut graph bit for bit."""
+    import torch
+    from ytvln.vilbert import BertConfig, BertEncoder
+    from helpers import cfg_dict
+    enc = BertEncoder(BertConfig(**cfg_dict("micro.json")))
+    w = torch.randn(5, 5, requires_grad=True)
+    x = torch.randn(3, 5)
+
+    def fwd(cut):
+        enc.cut_after = frozenset({"c0"} if cut else ())
+        enc._cuts = []
+        h1, h2 = torch.tanh(x @ w), torch.sin(x @ w.t())
+        h1, h2 = enc._cut("c0", h1, h2)
+        frozen = enc._cut("c0", x)                       # nothing to cut on a tensor without a gradient
+        assert frozen is x
+        return ((h1 * h2) @ w).sum() + (h1 ** 2).sum()
+
+    fwd(False).backward()
+    ref = w.grad.clone()
+    w.grad = None
+    loss = fwd(True)
+    (name, below, above), = enc._cuts
+    assert name == "c0" and len(below) == 2 and all(a.is_leaf and a.requires_grad for a in above)
+    loss.backward()                                      # phase 1: stops at the leaves
+    partial = w.grad.clone()
+    assert not torch.equal(partial, ref) and all(a.grad is not None for a in above)
+    torch.autograd.backward(below, [a.grad for a in above])     # phase 2
+    assert torch.allclose(w.grad, ref, rtol=0, atol=1e-6)
+    with torch.no_grad():
+        assert enc._cut("c0", torch.ones(2, requires_grad=True)).requires_grad      # no graph being built: untouched

@@ -76,6 +76,9 @@ def _worker(case, port, q):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
         collective, mode = case.split(":")
+        if mode == "phased3":           # explicit cut list: a text-only cut below the co-attention layer, the layer itself, an image-only cut above
+            os.environ["YTVLN_DP_CUTS"] = "t0,c0,v1"
+            mode = "phased"
         D.init_distributed(backend="nccl" if collective == "torch" else "gloo", force=True)
         assert dist.get_world_size() == 1 and dist.get_backend() == ("nccl" if collective == "torch" else "gloo")
         model, args = _build(dev)
@@ -96,9 +99,15 @@ def _worker(case, port, q):
             info["collectives"] = dp._reducer.collectives
         else:
             U.train_step(dp, opt, sched, batch, args, 0, all_options=True)
-            gs = D.GraphedTrainStep(dp, opt, lambda: U.train_step(dp, opt, None, batch, args, 0, all_options=True, optimizer_step=False)[0],
+            gs = D.GraphedTrainStep(dp, opt, lambda backward=None: U.train_step(dp, opt, None, batch, args, 0, all_options=True,
+                                                                                optimizer_step=False, backward=backward)[0],
                                     bucket_bytes=64 << 10, mode=mode)
             assert gs.exchange and len(gs._slices) > 1
+            if mode == "phased":
+                info["phases"] = len(gs.graphs)
+                info["groups"] = [sum(hi - lo for lo, hi in g) for g in gs._group_slices]
+                info["arena"] = int(opt.flat_grad().numel())
+                info["params"] = sum(p.numel() for p in model.parameters() if p.grad is not None or True)
             for step in range(2):
                 loss = gs.step(sched)
             assert torch.isfinite(loss).item()
@@ -115,7 +124,7 @@ def _worker(case, port, q):
         raise e
 
 
-@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "torch:eager", "torch:split"])
+@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "rccl:phased", "rccl:phased3", "torch:eager", "torch:split"])
 def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -129,6 +138,14 @@ def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())     # identity exchange, grad_scale 1: bit-identical
     if case.startswith("rccl"):
         assert "rccl" in os.path.basename(info["library"])
+    if case == "rccl:phased3":
+        assert info["phases"] == 4, info
+    if case in ("rccl:phased", "rccl:phased3"):
+        # micro config: 2 + 2 layers, one co-attention layer -> cuts after c0 (and t1 when the text block below it is that long); every
+        # group but the last is exchanged under the following phases, and together the groups cover every parameter that has a gradient
+        assert info["phases"] >= 2 and len(info["groups"]) == info["phases"]
+        assert all(g > 0 for g in info["groups"][:1]) and info["groups"][-1] > 0
+        assert sum(info["groups"]) <= info["arena"] and sum(info["groups"]) >= 0.95 * info["arena"], info
 
 
 def test_rccl_c_abi_collectives(dev, lib):
@@ -190,7 +207,7 @@ def test_bench_starts_its_own_ranks(dev, lib):
     out = _run_bench(["--gpus", "2"], {"YTVLN_DIST_BACKEND": "gloo"})
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_pairs"] == 2 * out["config"]["pairs_per_gpu"]
     assert np.isfinite(out["final_loss"]) and out["value"] > 0
-    assert "two hipGraphs" in out["config"]["execution"] or "eager" in out["config"]["execution"]
+    assert "two hipGraphs" in out["config"]["execution"] or "eager" in out["config"]["execution"]      # gloo data plane: the split form
 
 
 def test_bench_dp_path_over_the_c_abi_communicator(dev, lib):
@@ -198,5 +215,5 @@ def test_bench_dp_path_over_the_c_abi_communicator(dev, lib):
     out = _run_bench(["--gpus", "1", "--dp-selftest"], {})
     assert out["n_gpus"] == 1 and out["config"]["dp_selftest"] is True
     assert out["config"]["gradient_exchange"].startswith("ytvln_rccl_")
-    assert "two hipGraphs" in out["config"]["execution"], out["config"]["execution"]
+    assert "hipGraphs per step" in out["config"]["execution"] and "[phased;" in out["config"]["execution"], out["config"]["execution"]
     assert np.isfinite(out["final_loss"])

@@ -380,20 +380,22 @@ class DataParallel(nn.Module):
 
 
 class GraphedTrainStep:
-    """A training step replayed from hipGraphs with the gradient exchange between them:
+    """A training step replayed from hipGraphs with the gradient exchange outside them.  Three forms (`mode`, env `YTVLN_DP_GRAPH`):
 
-        graph A   forward, losses, backward, adoption of the stray gradients into the flat arena
-        exchange  all-reduce(SUM) of the arena in `bucket_bytes` slices over RCCL   (world > 1)
-        graph B   fused AdamW (1/world folded in)
+    "phased" (default with the C ABI's communicator): the backward pass is cut at encoder layer boundaries and captured as one graph per
+        phase; the gradients a phase completed are all-reduced on a communication stream while the following phases run -- the exchange
+        is hidden under backward except for the last group (the lowest layers and the embeddings).  See `_capture_phased`.
+    "split": graph A (forward, losses, backward, adoption of the stray gradients into the flat arena) | all-reduce(SUM) of the arena in
+        `bucket_bytes` slices on the SAME stream | graph B (fused AdamW, 1/world folded in).  Plain stream order, no events; the whole
+        exchange (1 GB over xGMI) is exposed.  The form used with a torch.distributed data plane.
+    "single": the exchange recorded INTO one graph with forward/backward and AdamW (RCCL collectives are capturable): one launch per step.
 
-    The host enqueues two graph launches and one RCCL group per step instead of ~1500 kernels, so N processes do not compete for
-    host cores.  With the C ABI's communicator the slices are enqueued on the SAME stream as the graphs (`ytvln_rccl_allreduce_slices_f32`,
-    one group): plain stream order, no events, no watchdog thread.  (The eager path overlaps the exchange with backward; here it follows
-    backward -- 1 GB over xGMI, a few ms against a >100 ms step.)  mode="single" (opt-in, `YTVLN_DP_GRAPH=single`) records the exchange
-    INTO one graph with forward/backward and AdamW -- RCCL collectives are capturable -- leaving one graph launch per step.
+    The host enqueues a handful of graph launches and RCCL groups per step instead of ~1500 kernels, so N processes do not compete for host
+    cores; no watchdog thread, no hidden stream.
 
-    `fwd_bwd()` must run forward + backward only (utils_init.train_step(..., optimizer_step=False)) on STATIC input tensors and
-    return the loss tensor; refill the inputs in place between steps.  Run >= 1 eager step first (arenas, allocator warm-up)."""
+    `fwd_bwd(backward=None)` must run forward + backward only (utils_init.train_step(..., optimizer_step=False, backward=backward)) on
+    STATIC input tensors and return the loss tensor; refill the inputs in place between steps.  Run >= 1 eager step first (arenas,
+    allocator warm-up)."""
 
     def __init__(self, model: nn.Module, optimizer, fwd_bwd: Callable[[], torch.Tensor], bucket_bytes: int = 256 << 20, group=None,
                  mode: Optional[str] = None):
@@ -402,11 +404,14 @@ class GraphedTrainStep:
         self.comm = dp.comm if dp is not None else None
         self.world = dp.world if dp is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.exchange = self.world > 1 or (dp is not None and dp.always_exchange)
-        self.mode = mode or os.environ.get("YTVLN_DP_GRAPH", "split")
-        if self.mode not in ("split", "single"):
-            raise ValueError(f"GraphedTrainStep mode {self.mode!r}: expected 'split' or 'single'")
+        # default: the phased backward (exchange under the rest of backward) whenever there is an exchange and the C ABI's communicator
+        # to run it on its own stream; otherwise the two-graph form with the exchange between the graphs
+        self.mode = mode or os.environ.get("YTVLN_DP_GRAPH") or ("phased" if (self.exchange and self.comm is not None) else "split")
+        if self.mode not in ("split", "single", "phased"):
+            raise ValueError(f"GraphedTrainStep mode {self.mode!r}: expected 'split', 'single' or 'phased'")
         if self.mode == "single" and self.exchange and self.comm is None:
             raise RuntimeError("mode='single' records the exchange into the graph: it needs the RCCL communicator of the C ABI")
+        self._model = model
         if optimizer.flat_grad() is None:
             raise RuntimeError("run at least one eager training step before capturing")
         optimizer.zero_grad()
@@ -420,6 +425,9 @@ class GraphedTrainStep:
         # thread_local: with the torch.distributed data plane RCCL's watchdog thread polls events while we capture; only this
         # thread's calls belong to the graph
         try:
+            if self.mode == "phased":
+                self._capture_phased(fwd_bwd, optimizer, flat, cap)
+                return
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
                 self.loss = fwd_bwd()
@@ -436,10 +444,133 @@ class GraphedTrainStep:
         finally:
             if dp is not None:
                 dp.require_backward_grad_sync = True
-        optimizer.zero_grad()
+            optimizer.zero_grad()
+            torch.cuda.synchronize()
+
+    # ---- phased backward: the exchange overlaps the rest of the backward pass -----------------------------------------------------
+    def _capture_phased(self, fwd_bwd, optimizer, flat, cap):
+        """The backward pass is cut at layer boundaries of the encoder (BertEncoder.cut_after) and captured as one graph per phase:
+
+            graph 0   forward, losses, backward of the heads and the layers above the last cut, adoption of THEIR stray gradients
+            graph k   backward from cut k down to the next one, adoption
+            graph B   fused AdamW
+
+        After graph k is enqueued the gradients it completed are all-reduced on a communication stream while graph k+1 .. run on the
+        compute stream; only the last group's exchange (embeddings + the lowest layers) is exposed.  Which parameter belongs to which
+        group is observed, not assumed: a post-accumulate hook records the phases in which every parameter received a gradient, and the
+        LAST one decides (a weight used on both sides of a cut, e.g. the word embedding tied to the LM decoder, goes with the later
+        phase).  Values are bit-identical to the uncut backward: a cut only detaches and re-attaches the hidden states."""
+        import gc
+        import inspect
+        if "backward" not in inspect.signature(fwd_bwd).parameters:
+            raise TypeError("mode='phased': fwd_bwd must accept backward=<callable(loss)> and pass it to train_step(..., backward=...)")
+        encs = [m for m in self._model.modules() if hasattr(m, "cut_after") and hasattr(m, "_cuts")]
+        if len(encs) != 1:
+            raise RuntimeError("mode='phased' needs exactly one encoder exposing cut points")
+        enc = encs[0]
+        spec = os.environ.get("YTVLN_DP_CUTS", "auto")
+        if spec == "auto":      # every co-attention layer, and every second layer of the text-only block below the first one
+            first_t = enc.t_biattention_id[0] if len(enc.t_biattention_id) else 0
+            names = [f"c{i}" for i in range(len(enc.c_layer))] + [f"t{i}" for i in range(1, first_t, 2)]
+        else:
+            names = [n for n in spec.split(",") if n]
+        enc.cut_after = frozenset(names)
+        params = [p for p in self._model.parameters() if p.requires_grad]
+        touched, phase = [], [0]
+        hooks = [p.register_post_accumulate_grad_hook(lambda q: touched.append((phase[0], q))) for p in params]
+        graphs = [torch.cuda.CUDAGraph()]
+        side = torch.cuda.Stream()
+
+        def end_phase():
+            optimizer.capture_adopt_some([q for ph, q in touched if ph == phase[0]])
+            graphs[-1].capture_end()
+            phase[0] += 1
+            graphs.append(torch.cuda.CUDAGraph())
+            graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+
+        def phased_backward(loss):
+            cuts = list(enc._cuts)
+            loss.backward()
+            for _, below, above in reversed(cuts):
+                end_phase()
+                pairs = [(b, a.grad) for b, a in zip(below, above) if a.grad is not None]
+                for a in above:
+                    a.grad = None
+                if pairs:
+                    torch.autograd.backward([b for b, _ in pairs], [g for _, g in pairs])
+            enc._cuts = []
+
         torch.cuda.synchronize()
+        gc.collect()
+        side.wait_stream(torch.cuda.current_stream())
+        capturing = False
+        try:
+            with torch.cuda.stream(side):
+                graphs[0].capture_begin(capture_error_mode="thread_local")
+                capturing = True
+                self.loss = fwd_bwd(backward=phased_backward)
+                optimizer.capture_adopt()
+                graphs[-1].capture_end()
+                capturing = False
+                self.graph_b = torch.cuda.CUDAGraph()
+                self.graph_b.capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+                capturing = True
+                optimizer.capture_update()
+                self.graph_b.capture_end()
+                capturing = False
+        finally:
+            for h in hooks:
+                h.remove()
+            if capturing:
+                with torch.cuda.stream(side):
+                    try:
+                        (graphs[-1] if not hasattr(self, "graph_b") or self.graph_b is None else self.graph_b).capture_end()
+                    except Exception:
+                        pass
+        torch.cuda.current_stream().wait_stream(side)
+        self.graphs = graphs
+        last = {}
+        for ph, q in touched:
+            last[id(q)] = (max(ph, last[id(q)][0]) if id(q) in last else ph, q)
+        groups = [[] for _ in graphs]
+        for ph, q in last.values():
+            r = optimizer.arena_range(q)
+            if r is not None:
+                groups[ph].append(r)
+        self._group_slices = []
+        for rng in groups:                      # merge adjacent slots, then cut into bucket-sized pieces
+            rng.sort()
+            merged = []
+            for o, n in rng:
+                if merged and merged[-1][1] == o:
+                    merged[-1][1] = o + n
+                else:
+                    merged.append([o, o + n])
+            self._group_slices.append([(lo, min(lo + cap, hi)) for a, hi in merged for lo in range(a, hi, cap)])
+        self._comm_stream = torch.cuda.Stream()
+        self._events = [torch.cuda.Event() for _ in graphs]
 
     def step(self, scheduler=None) -> torch.Tensor:
+        if self.mode == "phased":
+            cur = torch.cuda.current_stream()
+            flat = self.opt.flat_grad()
+            for k, g in enumerate(self.graphs):
+                g.replay()
+                if self.exchange and self._group_slices[k]:
+                    if self.comm is None:       # torch.distributed data plane: same groups, in stream order (no overlap; tests over gloo)
+                        for lo, hi in self._group_slices[k]:
+                            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                        continue
+                    self._events[k].record(cur)
+                    self._comm_stream.wait_event(self._events[k])
+                    self.comm.all_reduce_slices(flat, self._group_slices[k], stream=self._comm_stream)
+            if self.exchange and self.comm is not None:
+                cur.wait_stream(self._comm_stream)
+            self.opt.prepare_replay()
+            self.graph_b.replay()
+            if scheduler is not None:
+                scheduler.step()
+            return self.loss
         if self.mode == "single":
             self.opt.prepare_replay()                   # hyper-parameters land (stream-ordered) before the graph's AdamW nodes
             self.graph_a.replay()

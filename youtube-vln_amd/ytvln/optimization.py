@@ -255,6 +255,28 @@ class AdamW(Optimizer):
             raise RuntimeError("the set of parameters receiving gradients changed; cannot capture")
         self._ensure_arena()
 
+    def capture_adopt_some(self, params):
+        """Inside a capture, in the middle of a phased backward: bring the gradients of `params` (complete at this point, the others may
+        not exist yet) into their arena slots -- the partial form of capture_adopt()."""
+        if not torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("capture_adopt_some() is only meaningful while capturing a hipGraph")
+        if self._arena is None or self._launch is None:
+            raise RuntimeError("run at least one eager optimizer step before capturing a step into a graph")
+        fg, index = self._arena["g"], self._arena["index"]
+        base_g = fg.data_ptr()
+        with torch.no_grad():
+            for p in params:
+                if p.grad is None or id(p) not in index:
+                    continue
+                o, n = index[id(p)]
+                if p.grad.data_ptr() != base_g + 4 * o:
+                    fg[o:o + n].copy_(p.grad.reshape(-1))
+                    p.grad = fg[o:o + n].view(p.shape)
+
+    def arena_range(self, p):
+        """(offset, numel) of a parameter's slot in the flat arenas, or None."""
+        return None if self._arena is None else self._arena["index"].get(id(p))
+
     def capture_update(self):
         """Inside a capture: record the fused AdamW kernels (hyper-parameters come from prepare_replay())."""
         if not torch.cuda.is_current_stream_capturing():

@@ -165,10 +165,12 @@ def _loss_aware_step(model, batch, args, all_options, capacity_frac):
 
 
 def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=None, all_options=None,
-               loss_aware_heads: bool = False, capacity_frac: float = 0.25, optimizer_step: bool = True):
+               loss_aware_heads: bool = False, capacity_frac: float = 0.25, optimizer_step: bool = True, backward=None):
     """One iteration of train_epoch's body (utils_init.py:199-239): forward, loss composition in the reference's order,
     backward, and -- every gradient_accumulation_steps -- optimizer.step(); scheduler.step(); zero_grad().
-    Returns (loss, reduced_metrics) as device tensors; never synchronises the host."""
+    Returns (loss, reduced_metrics) as device tensors; never synchronises the host.
+    `backward` (optional callable taking the loss) replaces `loss.backward()` -- ytvln.distributed.GraphedTrainStep runs the backward
+    pass in phases through it."""
     reduced_metrics = {"loss": {}, "accuracy": {}}
     fused = {}
     if loss_aware_heads and (args.masked_language or args.masked_vision):
@@ -194,7 +196,10 @@ def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=N
             # data parallel: exchange the ACCUMULATED gradients once, during the last micro-step's backward (a bucket reduced after
             # the first micro-step would be summed over ranks and then have un-reduced local gradients added to it)
             model.require_backward_grad_sync = (step + 1) % accum == 0
-    loss.backward()
+    if backward is not None:
+        backward(loss)
+    else:
+        loss.backward()
     if not optimizer_step:          # forward/backward only (ytvln.distributed.GraphedTrainStep captures the update separately)
         return loss.detach(), reduced_metrics
     if (step + 1) % accum == 0:

@@ -473,6 +473,22 @@ class BertEncoder(nn.Module):
         self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(config.num_hidden_layers)])
         self.v_layer = nn.ModuleList([copy.deepcopy(v_layer) for _ in range(config.v_num_hidden_layers)])
         self.c_layer = nn.ModuleList([copy.deepcopy(connect_layer) for _ in range(len(config.v_biattention_id))])
+        # Autograd cut points for a backward pass that runs in phases (ytvln.distributed.GraphedTrainStep, mode "phased": the gradients
+        # of the layers above a cut are exchanged between the ranks while the layers below it are still running their backward).
+        # Names: "t<i>" / "v<i>" = after text / image layer i, "c<i>" = after co-attention layer i.  At a cut the hidden states are
+        # replaced by detached leaves; `_cuts` keeps (outputs below the cut, leaves above it) in forward order.  Values are unchanged.
+        self.cut_after = frozenset()
+        self._cuts = []
+
+    def _cut(self, name, *hidden):
+        if name not in self.cut_after or not torch.is_grad_enabled() or not any(h.requires_grad for h in hidden):
+            return hidden if len(hidden) > 1 else hidden[0]
+        below = [h for h in hidden if h.requires_grad]
+        above = [h.detach().requires_grad_() for h in below]
+        self._cuts.append((name, below, above))
+        it = iter(above)
+        out = tuple(next(it) if h.requires_grad else h for h in hidden)
+        return out if len(out) > 1 else out[0]
 
     def _set_probs(self, flag: bool):
         for m in self.modules():
@@ -486,22 +502,26 @@ class BertEncoder(nn.Module):
         self._set_probs(bool(output_all_attention_masks))
         v_start = t_start = 0
         all_t, all_v, att_t, att_v, att_c = [], [], [], [], []
+        self._cuts = []
+        cuts = bool(self.cut_after) and not (self.in_batch_pairs or self.FAST_MODE)
 
-        def run(layers, lo, hi, x, mask, sink, frozen_to):
+        def run(layers, lo, hi, x, mask, sink, frozen_to, tag):
             for idx in range(lo, hi):
                 if idx < frozen_to:
                     with torch.no_grad():
                         x, pr = layers[idx](x, mask)
                 else:
                     x, pr = layers[idx](x, mask)
+                if cuts:
+                    x = self._cut(f"{tag}{idx}", x)
                 if output_all_attention_masks:
                     sink.append(pr)
             return x
 
         for count, (v_end, t_end) in enumerate(zip(self.v_biattention_id, self.t_biattention_id)):
             assert self.fixed_t_layer <= t_end and self.fixed_v_layer <= v_end
-            image_embedding = run(self.v_layer, v_start, v_end, image_embedding, image_attention_mask, att_v, self.fixed_v_layer)
-            txt_embedding = run(self.layer, t_start, t_end, txt_embedding, txt_attention_mask, att_t, self.fixed_t_layer)
+            image_embedding = run(self.v_layer, v_start, v_end, image_embedding, image_attention_mask, att_v, self.fixed_v_layer, "v")
+            txt_embedding = run(self.layer, t_start, t_end, txt_embedding, txt_attention_mask, att_t, self.fixed_t_layer, "t")
             if count == 0 and self.in_batch_pairs:
                 # every text of the batch against every image of the batch: B -> B^2 rows (vilbert.py:771-778); row (i, j) = text i, image j
                 b, r_, hv = image_embedding.shape
@@ -521,12 +541,14 @@ class BertEncoder(nn.Module):
                     image_embedding, image_attention_mask, txt_embedding, txt_attention_mask, co_attention_mask, False)
                 if output_all_attention_masks:
                     att_c.append(co_probs)
+                if cuts:
+                    image_embedding, txt_embedding = self._cut(f"c{count}", image_embedding, txt_embedding)
             v_start, t_start = v_end, t_end
             if output_all_encoded_layers:
                 all_t.append(txt_embedding)
                 all_v.append(image_embedding)
-        image_embedding = run(self.v_layer, v_start, len(self.v_layer), image_embedding, image_attention_mask, att_v, 0)
-        txt_embedding = run(self.layer, t_start, len(self.layer), txt_embedding, txt_attention_mask, att_t, 0)
+        image_embedding = run(self.v_layer, v_start, len(self.v_layer), image_embedding, image_attention_mask, att_v, 0, "v")
+        txt_embedding = run(self.layer, t_start, len(self.layer), txt_embedding, txt_attention_mask, att_t, 0, "t")
         if not output_all_encoded_layers:
             all_t.append(txt_embedding)
             all_v.append(image_embedding)
