@@ -326,7 +326,8 @@ def main():
         if ok:
             step = graph_step
             how = (f"{len(gs.graphs) + 1} hipGraphs per step (forward + backward in {len(gs.graphs)} phases | AdamW), every phase's gradients all-reduced "
-                   f"on a communication stream under the next phases") if (dp_wrap and gs.mode == "phased") else \
+                   + ("on a communication stream under the next phases" if runner.comm is not None else "after its graph, in stream order")) \
+                if (dp_wrap and gs.mode == "phased") else \
                 "two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them"
             execution = "hipGraph replay of the captured step" if not dp_wrap else \
                 (f"{how} [{gs.mode}; exchange: {'ytvln_rccl_* C ABI' if runner.comm is not None else 'torch.distributed ' + dist.get_backend()}]")
