@@ -442,6 +442,9 @@ def main():
         "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / a.steps, 2),
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
     }
+    if dp_wrap and use_graph and getattr(gs, "mode", "") == "phased":
+        # MB of gradients per exchange group, in the order they go out (the last one is the exposed tail)
+        out["config"]["exchange_groups_mb"] = [round(4e-6 * sum(hi - lo for lo, hi in g), 1) for g in gs._group_slices]
     if a.h2d != "off":
         out["h2d"] = {"mode": a.h2d, "bytes_per_step": h2d_bytes, "note": "value INCLUDES the host->HBM upload of the batch; not the headline"}
     if "full" in a.workload and T == 80 and frames * boxes == 288 and not a.loss_aware_heads and a.precision in ("fp32", "fp32x3"):   # (FLOP count is the full-decode one)
