@@ -817,6 +817,42 @@ print("STREAMK_OK")
     assert "STREAMK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_gemm_splitk_xcd_layout_does_not_change_results(dev, lib):
+    """Split-K workgroups are numbered split-major per XCD (decode_tile; YTVLN_GEMM_SPLIT_MAP=0 restores the old split-fastest order): the
+    layout decides only WHERE a (tile, split) pair runs, so products, fused row sums and a beta = 1 accumulation are bit-identical
+    between the two orders (the knob is read once per process, hence the subprocesses)."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from ytvln import ops
+dev = torch.device("cuda", 0)
+h = hashlib.sha256()
+for (M, N, K, ta, tb) in [(768, 3072, 4480, 1, 0), (1024, 1024, 16128, 1, 0), (768, 768, 4480, 1, 0), (2304, 768, 4480, 1, 0), (1000, 520, 8192, 0, 1)]:
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    C = torch.randn(M, N, generator=g).to(dev)
+    C0 = C.clone()
+    rs = torch.empty(M, device=dev)
+    done = ops._gemm(A, A.stride(0), ta, B, B.stride(0), tb, C, N, M, N, K, beta=1.0, rowsum=rs if ta else None)
+    torch.cuda.synchronize()
+    h.update(C.cpu().numpy().tobytes())
+    if done: h.update(rs.cpu().numpy().tobytes())
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + C0.double()
+    assert float((C.double() - ref).abs().max()) / float(ref.abs().max()) < 1e-5
+print("DIGEST", h.hexdigest())
+""" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd")
+    digests = []
+    for m in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, YTVLN_GEMM_SPLIT_MAP=m), capture_output=True, text=True, timeout=300)
+        assert "DIGEST" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(r.stdout.split("DIGEST")[1].split()[0])
+    assert digests[0] == digests[1]
+
+
 @pytest.mark.parametrize("rows,cols", [(256, 128), (300, 200), (65, 1601), (4480, 768), (70, 30)])
 def test_cast_bf16_dual_equals_separate_stagings(dev, lib, rows, cols):
     """One pass producing both bf16 stagings == the plain and the transposing staging kernels, bit for bit (zero tails included)."""
