@@ -268,3 +268,48 @@ def test_encoder_cut_points_split_the_backward_without_changing_gradients():
     assert torch.allclose(w.grad, ref, rtol=0, atol=1e-6)
     with torch.no_grad():
         assert enc._cut("c0", torch.ones(2, requires_grad=True)).requires_grad      # no graph being built: untouched
+
+
+def test_drop_in_names_of_the_reference_modules_exist():
+    """The reference's loops import these names from the modules this package replaces (pretrain.py:12-13, train.py:12-13, vilbert.py:126,
+    optimization.py:64-105): they must resolve, and the small ones must behave."""
+    import math
+    import types
+    import pytest as _pytest
+    import torch
+    from ytvln import distributed as D, optimization as O, utils_init as U, vilbert as V
+    for mod, names in ((U, "val_args get_time get_model_input get_mask_options get_batch_size get_ranking_target get_vision_target "
+                           "get_linguistic_target get_loss_correct compute_metrics_independent train_epoch get_model_path save_model "
+                           "delete_model val_independent test_epoch val_epoch"),
+                       (O, "ConstantLRSchedule WarmupConstantSchedule WarmupLinearSchedule WarmupCosineSchedule "
+                           "WarmupCosineWithHardRestartsSchedule AdamW"),
+                       (V, "gelu swish ACT2FN BertConfig BertModel BertForMultiModalPreTraining BertPreTrainingHeads BertPreTrainedModel "
+                           "load_tf_weights_in_bert"),
+                       (D, "get_world_size get_rank get_local_rank init_distributed is_main_proc wrap_distributed_model set_cuda build_sampler "
+                           "all_reduce_and_rescale_tensors")):
+        for n in names.split():
+            assert hasattr(mod, n), (mod.__name__, n)
+    x = torch.linspace(-3, 3, 13)
+    assert torch.allclose(V.gelu(x), torch.nn.functional.gelu(x), atol=1e-6) and torch.allclose(V.swish(x), x * torch.sigmoid(x))
+    assert V.ACT2FN["gelu"] is V.gelu
+    ns = types.SimpleNamespace(masked_vision=False, masked_language=False, ranking=False, traj_judge=False, pretrain=True,
+                               not_traj_judge_data=False, shuffle_visual_features=False)
+    with _pytest.raises(ValueError):
+        U.val_args(ns)
+    ns.ranking = True
+    U.val_args(ns)
+    ns.pretrain, ns.traj_judge, ns.ranking = False, True, False
+    with _pytest.raises(ValueError):
+        U.val_args(types.SimpleNamespace(**{**vars(ns), "shuffle_visual_features": True}))
+    assert len(U.get_time()) == 16
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    s = O.WarmupCosineSchedule(opt, warmup_steps=2, t_total=10)
+    assert s.lr_lambda(1) == 0.5 and abs(s.lr_lambda(6) - 0.5) < 1e-12 and s.lr_lambda(10) < 1e-12
+    r = O.WarmupCosineWithHardRestartsSchedule(opt, warmup_steps=0, t_total=8, cycles=2.0)
+    assert r.lr_lambda(0) == 1.0 and abs(r.lr_lambda(4) - 1.0) < 1e-12 and abs(r.lr_lambda(2) - 0.5) < 1e-12 and r.lr_lambda(8) == 0.0
+    ts = [torch.ones(3), torch.full((2, 2), 4.0)]
+    D.all_reduce_and_rescale_tensors(ts, 2.0)
+    assert torch.equal(ts[0], torch.full((3,), 0.5)) and torch.equal(ts[1], torch.full((2, 2), 2.0))
+    sampler, pre = D.build_sampler(list(range(5)), False, 2, -1)
+    assert list(sampler) == [0, 1, 2, 3, 4] and pre(0) is None

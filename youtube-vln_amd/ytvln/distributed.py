@@ -49,6 +49,36 @@ def get_local_rank(args=None) -> int:
     return getattr(args, "local_rank", -1) if args is not None else -1
 
 
+def is_main_proc(args=None) -> bool:
+    """utils/distributed.py: rank 0 (or a single process)."""
+    return get_rank(0) == 0
+
+
+def build_sampler(dataset, is_train: bool, batch_size: int, local_rank: int):
+    """(sampler, pre_epoch) -- utils/distributed.py:156-181: a DistributedSampler over the process group when data parallel (shuffling and
+    `set_epoch` for training), Random / Sequential sampling otherwise.  One process per GPU: no batch-size scaling for nn.DataParallel."""
+    from torch.utils.data import RandomSampler, SequentialSampler
+    from torch.utils.data.distributed import DistributedSampler
+    if local_rank == -1 or not dist.is_initialized():
+        return (RandomSampler(dataset) if is_train else SequentialSampler(dataset)), (lambda epoch: None)
+    sampler = DistributedSampler(dataset, num_replicas=dist.get_world_size(), rank=dist.get_rank(), shuffle=is_train)
+    return sampler, sampler.set_epoch
+
+
+def all_reduce_and_rescale_tensors(tensors, rescale_denom) -> None:
+    """utils/distributed.py:184-214: SUM over ranks of a list of tensors as ONE flat collective, divided by `rescale_denom`, in place."""
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+    flat.div_(rescale_denom)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+
+
 def default_collective() -> str:
     """"rccl": the C ABI's own RCCL communicator (default on a HIP device); "torch": torch.distributed.all_reduce."""
     c = os.environ.get("YTVLN_DP_COLLECTIVE", "rccl" if torch.cuda.is_available() else "torch")

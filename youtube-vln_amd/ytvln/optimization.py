@@ -61,6 +61,37 @@ class WarmupLinearSchedule(LambdaLR):
         return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
 
 
+class WarmupCosineSchedule(LambdaLR):
+    """optimization.py:64-82: linear warm-up, then 0.5 * (1 + cos(2 pi cycles progress)) over the remaining steps (half a period by default),
+    floored at 0."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, cycles=0.5, last_epoch=-1):
+        self.warmup_steps, self.t_total, self.cycles = warmup_steps, t_total, cycles
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1.0, self.warmup_steps))
+        progress = float(step - self.warmup_steps) / float(max(1, self.t_total - self.warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(2.0 * math.pi * float(self.cycles) * progress)))
+
+
+class WarmupCosineWithHardRestartsSchedule(LambdaLR):
+    """optimization.py:85-105: linear warm-up, then `cycles` cosine decays from 1 to 0 with hard restarts; 0 once the schedule is over."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, cycles=1.0, last_epoch=-1):
+        self.warmup_steps, self.t_total, self.cycles = warmup_steps, t_total, cycles
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1, self.warmup_steps))
+        progress = float(step - self.warmup_steps) / float(max(1, self.t_total - self.warmup_steps))
+        if progress >= 1.0:
+            return 0.0
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(self.cycles) * progress) % 1.0))))
+
+
 class AdamW(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         if lr < 0.0:

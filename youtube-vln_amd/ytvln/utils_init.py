@@ -22,6 +22,21 @@ def pad_packed(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def val_args(args) -> None:
+    """utils_init.py:13-23: at least one objective; when fine-tuning, the trajectory-judgement task and `--shuffle_visual_features`
+    come together unless ranking / `--not_traj_judge_data` supplies the data."""
+    if not (args.masked_vision or args.masked_language or args.ranking or args.traj_judge):
+        raise ValueError("No training objective selected, add --masked_vision, --masked_language, --ranking, or --traj_judge")
+    if not args.pretrain and args.traj_judge and (bool(args.ranking or args.not_traj_judge_data) != bool(args.shuffle_visual_features)):
+        raise ValueError("fine-tuning with --traj_judge: drop --shuffle_visual_features, or run both tasks and pass it")
+
+
+def get_time() -> str:
+    """utils_init.py:26-27."""
+    from datetime import datetime
+    return datetime.now().strftime("%Y-%m-%d %H:%M")
+
+
 def get_model_input(batch, all_options=None):
     """utils_init.py:34-77: unpack the 16-tuple, drop padded options with opt_mask, return Lily.forward's 9 positionals.
 
@@ -279,6 +294,13 @@ def delete_model(model_save_path, save_name):
 
 def _to_device(batch, device):
     return tuple(t.to(device, non_blocking=True) if hasattr(t, "to") else t for t in batch)
+
+
+def val_independent(batch, outputs, task, args, logger, stats) -> None:
+    """utils_init.py:306-312: add one batch to stats[task] = [rows, summed loss, correct, batches] (device tensors, no host sync)."""
+    batch_size, _, loss, correct = get_loss_correct(batch, outputs, task, args, logger, False)
+    stats[task] += torch.stack([torch.full((), float(batch_size), device=loss.device), loss.float(), correct.float().reshape(()),
+                                torch.ones((), device=loss.device)])
 
 
 def test_epoch(epoch: int, model, tag, data_loader, writer, default_gpu, args, global_step, logger):

@@ -121,6 +121,26 @@ def _p(module: nn.Module, p: float) -> float:
     return float(p) if module.training else 0.0
 
 
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    """vilbert.py:113-119: the exact (erf) GELU.  Inside the model the activation is fused into the GEMM epilogue (ops.linear(..., "gelu"));
+    this stand-alone form exists for callers that import it."""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def swish(x: torch.Tensor) -> torch.Tensor:
+    """vilbert.py:122-123."""
+    return x * torch.sigmoid(x)
+
+
+ACT2FN = {"gelu": gelu, "relu": torch.nn.functional.relu, "swish": swish}        # vilbert.py:126
+
+
+def load_tf_weights_in_bert(model, tf_checkpoint_path):
+    """vilbert.py:58-110 reads a TensorFlow checkpoint through the `tensorflow` package.  Not part of the hot path and not available
+    here: convert the checkpoint to a PyTorch state dict once (the reference's own loader does that) and use `from_pretrained`."""
+    raise NotImplementedError("TensorFlow checkpoints are not read by this build; convert to a PyTorch state dict and use from_pretrained()")
+
+
 def _act_name(act) -> str:
     if not isinstance(act, str) or act not in ("gelu", "relu"):
         raise NotImplementedError(f"activation {act!r}: the HIP path implements 'gelu' (erf form) and 'relu'")
