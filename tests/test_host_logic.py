@@ -313,3 +313,15 @@ def test_drop_in_names_of_the_reference_modules_exist():
     assert torch.equal(ts[0], torch.full((3,), 0.5)) and torch.equal(ts[1], torch.full((2, 2), 2.0))
     sampler, pre = D.build_sampler(list(range(5)), False, 2, -1)
     assert list(sampler) == [0, 1, 2, 3, 4] and pre(0) is None
+
+
+def test_set_seed_restarts_the_dropout_stream():
+    import types
+    import torch
+    from ytvln import misc, ops
+    ops.DropoutState.manual_seed(77)
+    misc.set_seed(types.SimpleNamespace(seed=5, local_rank=2))
+    assert torch.initial_seed() == 7 and ops.DropoutState.seed is None          # the stream follows torch's seed again
+    misc.set_seed(types.SimpleNamespace(seed=0, local_rank=-1))                   # seed 0 = "do not seed" (utils/misc.py:37)
+    assert torch.initial_seed() == 7
+    assert misc.is_default_gpu(types.SimpleNamespace(local_rank=-1))
