@@ -111,10 +111,15 @@ def test_gemm_launch_planner_host_logic():
     assert plan(24192, 1024, 1024)[:2] != (256, 256)           # config 4: 95 x 4 = 380 tiles of 256x256 would leave half a wave idle
     assert plan(4480, 768, 3072) == (128, 128, 1)              # 210 tiles: one wave, no split-K round trip
     assert plan(4480, 1024, 768)[:2] == (64, 64)               # 280 128x128 tiles = 55 % of two waves -> small tiles
-    tm, tn, sp = plan(1024, 1024, 16128, transA=1)             # weight gradient: few tiles, long contraction -> deterministic split-K
-    assert (tm, tn) == (128, 128) and sp >= 4
+    # weight gradients (M-contiguous A): few tiles, long contraction -> deterministic split-K; since round 2 the 256x256 tile competes there
+    # (half the operand bytes per flop) and wins when tiles x splits fills one round of the 256 CUs
+    assert plan(1024, 1024, 16128, transA=1) == (256, 256, 16)
+    assert plan(2048, 1024, 16128, transA=1) == (256, 256, 8)
+    assert plan(768, 3072, 4480, transA=1) == (256, 256, 7)
+    assert plan(768, 768, 4480, transA=1)[:2] == (128, 128)    # 9 big tiles cannot fill the chip within 16 splits
     assert plan(1024, 1024, 16128, transA=1, epi=1)[2] == 1    # fused activations never split
-    assert plan(30522, 768, 4480, transA=1)[0] == 128          # an M-contiguous A never takes the 256-row tiles
+    tm, tn, sp = plan(30528, 768, 4480, transA=1)              # LM-head weight gradient: 360 big tiles, at most a shallow split
+    assert (tm, tn) == (256, 256) and sp <= 2
     assert lib.ytvln_gemm_plan(0, 8, 8, 0, 0, None, None, None) != 0
 
     def plan_x3(M, N, K, transA=0, epi=0):      # the three-bf16-term form of the fp32 GEMM has its own cost table

@@ -9,7 +9,7 @@ if os.environ.get("PRECISION"):
     ops.set_matmul_precision(os.environ["PRECISION"])      # fp32x3 | bf16
 SETS = {
     "wgrad": [(1024, 1024, 16128, 1, 0), (3072, 1024, 16128, 1, 0), (2048, 1024, 16128, 1, 0), (768, 3072, 4480, 1, 0), (3072, 768, 4480, 1, 0),
-              (2304, 768, 4480, 1, 0), (768, 768, 4480, 1, 0), (30522, 768, 4480, 1, 0)],
+              (2304, 768, 4480, 1, 0), (768, 768, 4480, 1, 0), (30522, 768, 4480, 1, 0), (30528, 768, 4480, 1, 0), (1024, 2048, 16128, 1, 0)],
     "dx": [(16128, 1024, 1024, 0, 0), (16128, 1024, 3072, 0, 0), (4480, 768, 3072, 0, 0), (4480, 3072, 768, 0, 0), (4480, 768, 2304, 0, 0),
            (4480, 768, 768, 0, 0)],
     "fwd": [(16128, 1024, 1024, 0, 1), (16128, 3072, 1024, 0, 1), (4480, 768, 3072, 0, 1), (4480, 3072, 768, 0, 1)],

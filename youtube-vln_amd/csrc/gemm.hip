@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct Plan { int tile; int splits; int streamk; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
 constexpr int SK_GRID = 512;                 // stream-K workgroups: two per CU, all resident
 
-static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0, bool x3 = false) {
+static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0, bool x3 = false, bool ta = false) {
     // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
     // us per 32-deep k-tile at the CU-exclusive rate: native fp32 MFMA | three-bf16-term form (fitted on 16128x1024x1024: the split's
@@ -790,7 +790,11 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     // (64x64 and 256x128 exist only for the native instruction: the three-term planner sees their native cost)
     static const double tk_f32[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tk_x3[5] = {1.61, 0.82, 0.55, 4.16, 4.94};
     static const double tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
-    const double* tk = x3 ? tk_x3 : tk_f32;
+    // native instruction, M-contiguous A (the weight-gradient layout: both operands k-major, fragments gathered by ds_read_b32): fitted in
+    // round 2 on the cfg-2 weight-gradient shapes (tools/r2_gpu37.sh) -- the 128x128 workgroups run at 2.3 us per k-tile there (half the
+    // flops per operand byte: ~3.7 TB/s of LDS-DMA at 120 TFLOP/s, the same delivery ceiling the fp32x3 256x256 kernel meets), the 256x256 at 7.3
+    static const double tk_f32_ta[5] = {2.3, 1.14, 0.55, 4.16, 7.3};
+    const double* tk = x3 ? tk_x3 : (ta ? tk_f32_ta : tk_f32);
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
     const int splits = (int)cdiv(K, kchunk);
     const double blocks = (double)(cdiv(M, bm[tile]) * cdiv(N, bn[tile])) * splits;
@@ -810,7 +814,7 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
 
 // big_ok: the 256-row tiles are only used with a K-contiguous A on the LDS-DMA path (an M-contiguous A needs four ds_read_b32 per
 // fragment and loses with the wide wave tiles: 121 -> 99 TFLOP/s on 30522x768x4480).
-static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool sk_ok = false, bool x3 = false) {
+static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool sk_ok = false, bool x3 = false, bool ta = false) {
     Plan best = {0, 1, 0};
     double best_t = 1e30;
     const int force_tile = getenv("YTVLN_GEMM_TILE") ? atoi(getenv("YTVLN_GEMM_TILE")) : -1;       // experiment knobs
@@ -819,10 +823,13 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
     for (int tile = 0; tile < 5; ++tile) {
         if (force_tile >= 0 && tile != force_tile) continue;
         if (tile >= 3 && (!big_ok || big < tile - 2 || M < 256)) continue;
-        const int smax = ((tile == 0 || (tile == 4 && x3)) && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
+        if (ta && tile == 3) continue;          // (256x128 was never measured with an M-contiguous A)
+        // split-K: 128x128 always; 256x256 in the three-term form and -- round 2 -- for the native weight-gradient layout (ta):
+        // 1024x1024x16128 323 -> 305 us, 2048x1024x16128 551 -> 505, 768x3072x4480 190 -> 178 (16 x 16, 32 x 8, 36 x 7 workgroups)
+        const int smax = ((tile == 0 || (tile == 4 && (x3 || ta))) && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
-            const double t = plan_cost(M, N, K, tile, sp, epilogue, x3);
+            const double t = plan_cost(M, N, K, tile, sp, epilogue, x3, ta);
             // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
             if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp, 0}; }
         }
@@ -1066,7 +1073,8 @@ using namespace ytvln;
 extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
     YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan: bad argument");
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
-    const Plan p = plan_gemm(M, N, K, epilogue, !transA, false);
+    static const int big_ta = getenv("YTVLN_GEMM_BIG_TA") ? atoi(getenv("YTVLN_GEMM_BIG_TA")) : 1;
+    const Plan p = plan_gemm(M, N, K, epilogue, !transA || big_ta, false, false, transA && big_ta);
     *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
     return 0;
 }
@@ -1081,9 +1089,10 @@ extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue,
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
-    const int splits = std::max(std::max(plan_splits(M, N, K, epilogue), std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
-                                                                                      plan_gemm(M, N, K, epilogue, true, false, true).splits)),
-                                plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points and the fp32x3 plans
+    const int splits = std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, false, true).splits),
+                                         std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
+                                                  plan_gemm(M, N, K, epilogue, true, false, true).splits)),
+                                plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points, either A layout and the fp32x3 plans
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
     if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
     return need;
@@ -1127,8 +1136,12 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     // three-term form: the 256x256 tile also takes an M-contiguous A (the split's VALU work dominates the four ds_read_b32 per fragment)
     // and split-K: 1024x1024x16128 144 -> 186, 4480x768x3072 136 -> 171 TFLOP/s (YTVLN_X3_BIG_TA=0 restores the native rule)
     static const int x3_big_ta = getenv("YTVLN_X3_BIG_TA") ? atoi(getenv("YTVLN_X3_BIG_TA")) : 1;
-    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && (!transA || (g.x3 && x3_big_ta)), g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems(),
-                          g.x3 && g.fast);
+    // native instruction with an M-contiguous A (weight gradients): 256x256 tiles + split-K compete with 128x128 since round 2
+    // (YTVLN_GEMM_BIG_TA=0 restores the 128x128-only rule)
+    static const int big_ta = getenv("YTVLN_GEMM_BIG_TA") ? atoi(getenv("YTVLN_GEMM_BIG_TA")) : 1;
+    const bool ta_native = g.fast && transA && !g.x3 && big_ta;
+    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && (!transA || (g.x3 && x3_big_ta) || ta_native),
+                          g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems(), g.x3 && g.fast, ta_native);
     if (plan.streamk) {
         g.tiles_m = (int)cdiv(M, 128); g.tiles_n = (int)cdiv(N, 128); g.ntiles = g.tiles_m * g.tiles_n;
         g.splits = 1; g.kchunk = g.Kloop; g.ws = workspace;
@@ -1157,7 +1170,7 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
         plan.splits = 1;
         double bt = 1e30;
         for (int tile = 0; tile < 3; ++tile) {
-            const double t = plan_cost(M, N, K, tile, 1, 0, g.x3 != 0);
+            const double t = plan_cost(M, N, K, tile, 1, 0, g.x3 != 0, ta_native);
             if (t < bt * 0.98) { bt = t; plan.tile = tile; }
         }
     }
