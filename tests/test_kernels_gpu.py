@@ -535,7 +535,8 @@ def test_gemm_zero_padded_tails(dev, lib):
 @pytest.mark.parametrize("M,N,K,ta,tb,epi", [
     (256, 192, 128, 0, 1, 0), (300, 200, 100, 0, 1, 0), (300, 200, 100, 0, 0, 0), (300, 200, 100, 1, 0, 0), (260, 132, 72, 1, 1, 0),
     (512, 384, 256, 0, 1, 1), (200, 1601, 320, 0, 1, 0), (128, 256, 4096, 1, 0, 0),
-    (3600, 3592, 128, 0, 1, 0), (3592, 3600, 192, 1, 0, 0)])      # the last two run on the 256x256 tile (ragged last tile row / column)
+    (3600, 3592, 128, 0, 1, 0), (3592, 3600, 192, 1, 0, 0),       # these two run on the 256x256 tile (ragged last tile row / column)
+    (1024, 768, 16384, 1, 0, 0), (1000, 520, 12288, 1, 0, 0)])    # weight-gradient shapes: 256x256 tiles with split-K (12 x 21, 12 x 21 ragged)
 def test_gemm_bf16_staged(dev, lib, M, N, K, ta, tb, epi):
     """bf16-staged projections (BASELINE config 5): exact product of the bf16-rounded operands, accumulated in fp32.
     Reference: the same rounded operands multiplied in fp64.  Tolerance = fp32 accumulation noise, 2e-6 * sqrt(K) * |a||b|."""

@@ -870,6 +870,22 @@ static int plan_splits_bf16(int M, int N, int K, int epilogue) {
     return best;
 }
 
+// Round 2: with few output tiles and a long contraction (the bf16 weight gradients: K = all rows of the batch) the 256x256 tile with split-K
+// beats 128x128 with split-K -- half the operand bytes per flop, and the bf16 kernels are bound by operand delivery, not by the matrix
+// pipe.  Taken when tiles256 x splits fills most of ONE round of the 256 CUs with at least 8 k-tiles per split; YTVLN_BF16_BIG_SPLIT=0
+// restores the 128x128 rule.  K in 4-byte words.
+static int plan_splits_bf16_any(int M, int N, int K, int epilogue, bool* big) {
+    static const int on = getenv("YTVLN_BF16_BIG_SPLIT") ? atoi(getenv("YTVLN_BF16_BIG_SPLIT")) : 1;
+    *big = false;
+    const int base = plan_splits_bf16(M, N, K, epilogue);
+    if (!on || epilogue != YTVLN_EPI_NONE || M < 256 || N < 256 || base < 2) return base;
+    const int64_t t256 = cdiv(M, 256) * cdiv(N, 256);
+    if (t256 >= 200) return base;
+    const int sp = (int)std::min<int64_t>(256 / t256, K / 256);
+    if (sp >= 2 && t256 * sp >= 200) { *big = true; return sp; }
+    return base;
+}
+
 template <int BM, int BN>
 static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.tiles_m = (int)cdiv(g.M, BM);
@@ -1055,8 +1071,8 @@ static bool bf16_big_tile(const GemmArgs& g) {
     return b256 >= 200.0 && e256 >= e128 - 0.05;
 }
 
-static void launch_bf16(GemmArgs& g, hipStream_t s) {
-    const bool big = bf16_big_tile(g);
+static void launch_bf16(GemmArgs& g, hipStream_t s, bool big_split = false) {
+    const bool big = big_split || bf16_big_tile(g);
     const int bt = big ? 256 : 128;
     g.tiles_m = (int)cdiv(g.M, bt);
     g.tiles_n = (int)cdiv(g.N, bt);
@@ -1089,10 +1105,12 @@ extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue,
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
+    bool big_unused = false;
     const int splits = std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, false, true).splits),
                                          std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
                                                   plan_gemm(M, N, K, epilogue, true, false, true).splits)),
-                                plan_splits_bf16(M, N, K, epilogue));     // covers both GEMM entry points, either A layout and the fp32x3 plans
+                                std::max(plan_splits_bf16(M, N, K, epilogue), plan_splits_bf16_any(M, N, K, epilogue, &big_unused)));
+    // (covers both GEMM entry points, either A layout, the fp32x3 plans and both bf16 split rules)
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
     if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
     return need;
@@ -1279,14 +1297,18 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr; g.x3 = 0;
     g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
-    const int want = plan_splits_bf16(M, N, K / 2, epilogue);
+    bool big_split = false;
+    int want = plan_splits_bf16_any(M, N, K / 2, epilogue, &big_split);
+    if (want > 1 && !(workspace && workspace_elems >= (int64_t)want * M * N)) { big_split = false; want = plan_splits_bf16(M, N, K / 2, epilogue); }
     if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
         g.kchunk = (int)cdiv(cdiv(g.Kloop, want), BK) * BK;
         g.splits = (int)cdiv(g.Kloop, g.kchunk);
         g.ws = workspace;
+    } else {
+        big_split = false;
     }
     hipStream_t s = as_stream(stream);
-    launch_bf16(g, s);
+    launch_bf16(g, s, big_split);
     if (g.splits > 1) {
         const int64_t total = (int64_t)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
