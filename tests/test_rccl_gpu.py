@@ -111,6 +111,8 @@ def _worker(case, port, q):
             for step in range(2):
                 loss = gs.step(sched)
             assert torch.isfinite(loss).item()
+            if mode == "phased":        # the cut points are gone once the phases are recorded: an eager step sees the uncut graph
+                assert all(not m.cut_after for m in model.modules() if hasattr(m, "cut_after"))
         torch.cuda.synchronize()
         if dp.comm is not None:
             dp.comm.check_async_error()

@@ -9,8 +9,9 @@ if os.environ.get("YTVLN_LIB"):          # experiment builds (e.g. scratch/lib_p
     _lib.LIB_PATH = os.path.abspath(os.environ["YTVLN_LIB"])
 from ytvln import ops
 dev = torch.device("cuda", 0)
-N = 56
-cases = [("img self", 8, 128, 288, 288), ("co t->v", 8, 128, 80, 288), ("co v->t", 8, 128, 288, 80), ("txt self", 12, 64, 80, 80)]
+N = int(os.environ.get("PAIRS_N", "56"))            # PAIRS_N=224 REGIONS=576: the cfg-5 shapes
+RG = int(os.environ.get("REGIONS", "288"))
+cases = [("img self", 8, 128, RG, RG), ("co t->v", 8, 128, 80, RG), ("co v->t", 8, 128, RG, 80), ("txt self", 12, 64, 80, 80)]
 only = os.environ.get("CASES")          # e.g. CASES="co" -> only the BertBiAttention shapes
 if only:
     cases = [c for c in cases if c[0].startswith(only)]
@@ -44,7 +45,7 @@ for name, h, d, Tq, Tk in cases:
 
 # both BertBiAttention directions in ONE launch per kernel (ytvln_attn_fwd_pair / ytvln_attn_bwd_pair), as CoAttentionFn runs them
 if not only or only.startswith("co"):
-    h, d, T, R = 8, 128, 80, 288
+    h, d, T, R = 8, 128, 80, RG
     Hb = h * d
     q1, kv1 = torch.randn(N * R, Hb, device=dev), torch.randn(N * R, 2 * Hb, device=dev)
     q2, kv2 = torch.randn(N * T, Hb, device=dev), torch.randn(N * T, 2 * Hb, device=dev)

@@ -551,6 +551,10 @@ class GraphedTrainStep:
         finally:
             for h in hooks:
                 h.remove()
+            # the cut points exist only while the phases are being recorded: an eager step taken later must see the uncut graph
+            # (a plain loss.backward() stops at the first cut)
+            enc.cut_after = frozenset()
+            enc._cuts = []
             if capturing:
                 with torch.cuda.stream(side):
                     try:
