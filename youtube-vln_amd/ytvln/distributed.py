@@ -436,7 +436,11 @@ class GraphedTrainStep:
         self.exchange = self.world > 1 or (dp is not None and dp.always_exchange)
         # default: the phased backward (exchange under the rest of backward) whenever there is an exchange and the C ABI's communicator
         # to run it on its own stream; otherwise the two-graph form with the exchange between the graphs
-        self.mode = mode or os.environ.get("YTVLN_DP_GRAPH") or ("phased" if (self.exchange and self.comm is not None) else "split")
+        explicit = mode or os.environ.get("YTVLN_DP_GRAPH")
+        self.mode = explicit or ("phased" if (self.exchange and self.comm is not None) else "split")
+        if not explicit and self.mode == "phased" and \
+                sum(1 for m in model.modules() if hasattr(m, "cut_after") and hasattr(m, "_cuts")) != 1:
+            self.mode = "split"             # a model without the encoder's cut points: the two-graph form
         if self.mode not in ("split", "single", "phased"):
             raise ValueError(f"GraphedTrainStep mode {self.mode!r}: expected 'split', 'single' or 'phased'")
         if self.mode == "single" and self.exchange and self.comm is None:
