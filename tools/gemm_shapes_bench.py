@@ -17,6 +17,7 @@ SETS = {
 SETS["fwddx"] = [s for s in SETS["dx"] + SETS["fwd"] if s[0] == 4480] + [(4480, 2304, 768, 0, 1), (4480, 1024, 768, 0, 1), (4480, 768, 1024, 0, 1), (4480, 768, 1024, 0, 0)]
 SETS["cfg4"] = [(24192, 1024, 1024, 0, 1), (24192, 1024, 1024, 0, 0), (24192, 3072, 1024, 0, 1), (24192, 1024, 3072, 0, 0), (24192, 2048, 1024, 0, 1),
                 (7680, 768, 768, 0, 1), (7680, 2304, 768, 0, 1), (7680, 3072, 768, 0, 1), (7680, 768, 3072, 0, 1), (7680, 768, 3072, 0, 0), (7680, 1024, 768, 0, 1)]
+SETS["probe"] = [(16128, 1024, 1024, 0, 1), (16128, 1024, 1024, 0, 0), (4480, 768, 3072, 0, 1), (4480, 3072, 768, 0, 1), (4480, 2304, 768, 0, 1), (1024, 1024, 16128, 1, 0), (768, 768, 4480, 1, 0)]
 which = os.environ.get("SHAPES", "all")
 shapes = sum(SETS.values(), []) if which == "all" else SETS[which]
 
