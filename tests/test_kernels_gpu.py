@@ -872,6 +872,8 @@ def test_cast_bf16_dual_colsum_rides_on_the_staging(dev, lib, rows, cols):
     """bf16 mode's bias gradient: the staging pass that reads dY also leaves per-64-row column sums; finished by colsum they equal the
     fp64 column sums to fp32 rounding, the stagings are bit-identical to the plain dual pass, and two runs agree bit for bit."""
     from ytvln import ops
+    if not ops._FUSED_BIAS_GRAD:
+        pytest.skip("YTVLN_FUSED_BIAS_GRAD=0: every bias gradient goes through ytvln_colsum_f32")
     g = torch.Generator().manual_seed(rows * 7 + cols)
     x = (torch.randn(rows, cols + 8, generator=g) * 3 + 0.5).to(dev)[:, :cols]
     (p0, _), (t0, _), done0 = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
@@ -920,6 +922,8 @@ def test_gemm_rowsum_rides_on_the_weight_gradient(dev, lib, M, N, K, expect):
     Also: the product itself is unchanged by the extra output, and repeated launches are bit-identical (fixed summation order)."""
     import ctypes
     from ytvln import _lib, ops
+    if not ops._FUSED_BIAS_GRAD:
+        pytest.skip("YTVLN_FUSED_BIAS_GRAD=0: every bias gradient goes through ytvln_colsum_f32")
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     dY = torch.randn(K, M, generator=g).to(dev)          # A operand stored [K, M]: transA = 1
     X = torch.randn(K, N, generator=g).to(dev)
