@@ -409,6 +409,13 @@ def main():
     elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)
     final_loss = float(loss)
     assert np.isfinite(final_loss), "training diverged"
+    # data parallel: after the timed steps every replica must hold the same parameters (each rank saw different data, so this holds only
+    # if every gradient was exchanged): max - min over ranks of a checksum of all parameters, 0.0 when the replicas are bit-identical
+    replica_spread = None
+    if dp_wrap and not infer:
+        with torch.no_grad():
+            chk = float(sum(p.detach().double().sum() for p in model.parameters()))
+        replica_spread = control_reduce(chk, dist.ReduceOp.MAX) - control_reduce(chk, dist.ReduceOp.MIN)
     if infer:
         execution = "eager launches, eval mode, forward only"
     roofline_note = "HIP events around every GEMM launch during the timed steps"
@@ -442,6 +449,8 @@ def main():
         "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / a.steps, 2),
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
     }
+    if replica_spread is not None:
+        out["config"]["replica_checksum_spread"] = replica_spread
     if dp_wrap and use_graph and getattr(gs, "mode", "") == "phased":
         # MB of gradients per exchange group, in the order they go out (the last one is the exposed tail)
         out["config"]["exchange_groups_mb"] = [round(4e-6 * sum(hi - lo for lo, hi in g), 1) for g in gs._group_slices]

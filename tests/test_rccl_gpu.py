@@ -208,6 +208,7 @@ def test_bench_starts_its_own_ranks(dev, lib):
     (2 ranks on the single test GPU need the gloo exchange; on an N-GPU node the same command runs the RCCL communicator.)"""
     out = _run_bench(["--gpus", "2"], {"YTVLN_DIST_BACKEND": "gloo"})
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_pairs"] == 2 * out["config"]["pairs_per_gpu"]
+    assert out["config"]["replica_checksum_spread"] == 0.0          # two ranks, different data, identical parameters after the steps
     assert np.isfinite(out["final_loss"]) and out["value"] > 0
     assert "two hipGraphs" in out["config"]["execution"] or "eager" in out["config"]["execution"]      # gloo data plane: the split form
 
