@@ -12,7 +12,8 @@ Prints ONE JSON line (rank 0).  Besides the driver contract it carries
   roofline     -- the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their HIP-event time, measured
                   live on the launch stream during the timed steps, against the 157.3 TFLOP/s fp32 matrix peak;
   variants     -- (N = 1, default precision only; NOT the headline) the same captured step re-timed with the opt-in fp32x3 projections
-                  (fp32 operands, three exact bf16 terms per value, six bf16 MFMAs per product; DESIGN.md 5a); --no-variants skips it;
+                  (fp32 operands, three exact bf16 terms per value, six bf16 MFMAs per product) and with bf16 operands
+                  (the arithmetic of BASELINE configs[4]); --no-variants skips them;
   cpu_baseline -- the CPU oracle (a port of the reference's path, oracle/vilbert_ref.py) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only).
 
@@ -65,7 +66,7 @@ def parse():
     ap.add_argument("--workload", default="cfg2_full_pretrain_bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--bs", type=int, default=None, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) fp32x3 measurement of the default run")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra (non-headline) fp32x3 / bf16 measurements of the default run")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="auto|on: replay the step from hipGraphs (1 GPU: one graph; N GPUs: two graphs around the RCCL all-reduce), falling back to eager launches if capture fails; off: eager launches")
@@ -496,32 +497,37 @@ def main():
     if world == 1 and not dp_wrap and a.precision == "fp32" and use_graph and a.h2d == "off" and not a.no_variants:
         # NOT the headline: the same captured step with the opt-in fp32x3 projections (fp32 operands, three exact bf16 terms per value,
         # six bf16 MFMAs per product; same parity bar as the native instruction), timed after everything above.
-        try:
-            yt_ops.set_matmul_precision("fp32x3")
-            base = a.warmup + a.steps + 8
+        def time_variant(mode, base):
+            """pairs/s and ms/step of the same step captured again under another projection arithmetic (after the headline is timed)"""
+            yt_ops.set_matmul_precision(mode)
             for i in range(2):
                 eager_step(base + i)
             torch.cuda.synchronize()
-            g3 = torch.cuda.CUDAGraph()
-            st3 = {}
-            with torch.cuda.graph(g3):
-                st3["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
+            gv = torch.cuda.CUDAGraph()
+            stv = {}
+            with torch.cuda.graph(gv):
+                stv["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
                                                         loss_aware_heads=a.loss_aware_heads)
             torch.cuda.synchronize()
 
-            def step3():
+            def stepv():
                 opt.prepare_replay()
-                g3.replay()
+                gv.replay()
                 sched.step()
             for _ in range(2):
-                step3()
+                stepv()
             torch.cuda.synchronize()
-            t3 = time.perf_counter()
+            tv = time.perf_counter()
             for _ in range(a.steps):
-                step3()
+                stepv()
             torch.cuda.synchronize()
-            e3 = time.perf_counter() - t3
-            assert np.isfinite(float(st3["loss"])), "fp32x3 variant diverged"
+            ev = time.perf_counter() - tv
+            assert np.isfinite(float(stv["loss"])), f"{mode} variant diverged"
+            del gv
+            return round(bs * K * a.steps / ev, 3), round(1000.0 * ev / a.steps, 3)
+
+        try:
+            v3, ms3 = time_variant("fp32x3", a.warmup + a.steps + 8)
             # accuracy evidence in the same line: one projection-sized product in both arithmetics against the fp64 product
             gq = torch.Generator(device="cpu").manual_seed(7)
             Aq = torch.randn(4096, 1024, generator=gq).to(dev)
@@ -537,13 +543,20 @@ def main():
             if "roofline" in out:
                 out["roofline"]["trace_note"] = ("in a kernel trace of this command the headline kernel is every gemm_dma_kernel<..., false, false> "
                                                  "instantiation; the <..., false, true> launches belong to variants.fp32x3 (--no-variants omits them)")
-            out["variants"] = {"fp32x3": {"value": round(bs * K * a.steps / e3, 3), "unit": "pairs/s", "ms_per_step": round(1000.0 * e3 / a.steps, 3),
+            out["variants"] = {"fp32x3": {"value": v3, "unit": "pairs/s", "ms_per_step": ms3,
                                           "note": "opt-in --precision fp32x3, not the headline: fp32 operands split exactly into 3 bf16 terms in "
                                                   "registers, 6 bf16 MFMAs per product, f32 accumulate; meets the fp32 parity bar (DESIGN.md 5a)",
                                           "gemm_4096x1024x1024_max_err_over_max_vs_f64": {"native_f32_mfma": float(f"{errs['fp32']:.3e}"),
                                                                                           "fp32x3": float(f"{errs['fp32x3']:.3e}")}}}
         except Exception as e:      # never let the extra measurement endanger the headline line
             out["variants"] = {"fp32x3": {"error": f"{type(e).__name__}: {e}"}}
+        try:        # bf16 operands on the MFMA (the arithmetic of BASELINE configs[4], the reference's --amp analogue) at the headline shape
+            vb, msb = time_variant("bf16", a.warmup + a.steps + 16)
+            out.setdefault("variants", {})["bf16"] = {"value": vb, "unit": "pairs/s", "ms_per_step": msb,
+                                                      "note": "opt-in --precision bf16, not the headline: bf16-staged projections and bf16-operand "
+                                                              "attention, f32 accumulate / activations / master weights (parity: the cfg-5 goldens, bf16 bar)"}
+        except Exception as e:
+            out.setdefault("variants", {})["bf16"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             yt_ops.set_matmul_precision("fp32")
     if rank == 0 and world == 1 and not dp_wrap and not a.no_cpu_baseline:
