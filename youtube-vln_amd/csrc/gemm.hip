@@ -14,6 +14,9 @@
 //  bf16-staged operands (BF16) and in the three-bf16-term form of fp32 (X3, YTVLN_GEMM_SPLIT_BF16X3).)
 #include "common.h"
 #include <algorithm>
+#include <vector>
+#include <type_traits>
+#include <utility>
 #include <stdlib.h>
 
 namespace ytvln {
@@ -39,6 +42,8 @@ struct GemmArgs {
     float* asum;          // optional: asum[m] = sum_k op(A)[m, k] (bias gradient riding on the weight-gradient GEMM); M-contiguous A, LDS-DMA path only
     float* asum_ws;       // split-K: per-split partial row sums [splits][M], reduced in a fixed order by splitk_reduce_kernel
     int split_map;        // 1: split-K workgroups are laid out split-major per XCD (see decode_tile)
+    unsigned long long* dbg;  // YTVLN_GEMM_DBG: per-workgroup clocks {entry, loop start, loop end, exit} (s_memrealtime, 100 MHz) + shader cycles of the loop
+    int probe;            // timing probes of gemm_sw_kernel (YTVLN_GEMM_PROBE; wrong results by construction): 1 no operand DMA, 2 no LDS fragment reads
 };
 
 constexpr int BK = 32;
@@ -186,6 +191,9 @@ __device__ __forceinline__ void epilogue_body(const GemmArgs& g, f32x16 (&acc)[T
                     cp0[(int64_t)dr * g.ldc] = v;
                 }
             }
+            // big wave tiles (gemm_sw_kernel: up to 4 x 4 sub-tiles, accumulators in AGPRs): without a fence hipcc hoists the accumulator
+            // reads and address arithmetic of ALL sub-tiles to the top and spills them to scratch
+            if constexpr (TM * TN > 8) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -350,6 +358,11 @@ struct DmaTile {
     }
 };
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -462,6 +475,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
     };
 
+    unsigned long long dbg_t0 = 0, dbg_c0 = 0;
+    if (g.dbg) { dbg_t0 = __builtin_amdgcn_s_memrealtime(); dbg_c0 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t);
@@ -549,6 +564,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
         }
     }
+    unsigned long long dbg_t2 = 0, dbg_c2 = 0;
+    if (g.dbg) { dbg_t2 = __builtin_amdgcn_s_memrealtime(); dbg_c2 = __builtin_amdgcn_s_memtime(); }
     if constexpr (!A_KC && !BF16 && !X3) {
         if (do_asum) {
 #pragma unroll
@@ -563,14 +580,357 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
     }
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
+    if (g.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+            d[0] = dbg_t0; d[1] = dbg_t0; d[2] = dbg_t2; d[3] = t3; d[4] = dbg_c2 - dbg_c0; d[5] = 0; d[6] = nk;
+        }
+    }
+}
+
+// Epilogue of the big-wave-tile kernels (gemm_sw_kernel): the wave's accumulators go through LDS (the operand ring is free by then) so that
+// the output leaves as 16-byte row segments -- one global_store_dwordx4 per lane covers two (TN = 4) or four (TN = 2) 512 / 256-byte row
+// pieces per wave instruction instead of sixteen 4-byte stores per 32 x 32 sub-tile -- and so that bias / activation / beta work runs in a
+// small run-time loop over rows instead of a fully unrolled, ten-times specialised store sequence (the unrolled form of a 4 x 4 sub-tile
+// wave is ~1 MB of code per kernel and spills).  `wlds`: this wave's private LDS region, 64 x (32 TN) floats; two passes for TM = 4.
+// Same arithmetic per element as epilogue_body (bias add, then activation, then beta * old), so results are bit-identical.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* __restrict__ wlds, int row0, int col0, int lane, int split) {
+    constexpr int W = 32 * TN, W4 = W / 4;              // floats / 16-byte groups per staged row
+    constexpr int IB = TM >= 2 ? 2 : 1;                 // 32-row blocks per pass
+    constexpr int RPI = 64 / W4;                        // rows covered by one wave-wide 16-byte access
+    const int l31 = lane & 31, half = lane >> 5;
+    const bool partial = g.splits > 1;
+    float* const Cb = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
+    const int64_t ldc = partial ? g.N : g.ldc;
+    const int epi = partial ? YTVLN_EPI_NONE : g.epilogue;
+    const float beta = partial ? 0.f : g.beta;
+    const float* bias = partial ? nullptr : g.bias;
+    const int c4 = lane % W4, rsub = lane / W4;
+    const int col = col0 + 4 * c4;
+    const bool vec = (g.N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 &&
+                     (epi == YTVLN_EPI_NONE || epi == YTVLN_EPI_RELU || g.aux == nullptr ||
+                      ((g.ldaux & 3) == 0 && (reinterpret_cast<uintptr_t>(g.aux) & 15) == 0));
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = col + u < g.N ? bias[col + u] : 0.f;
+    }
+    static_for<TM / IB>([&](auto PASS) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(PASS)::value * IB;       // (compile-time: a run-time index would move the accumulators to scratch memory)
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wlds[(32 * ii + (r & 3) + 8 * (r >> 2) + 4 * half) * W + 32 * j + l31] = acc[i0 + ii][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rbase = row0 + 32 * i0;
+        auto rows = [&](auto EPI_TAG) __attribute__((always_inline)) {
+            constexpr int EPI = decltype(EPI_TAG)::value;
+            constexpr bool AUXLD = EPI == YTVLN_EPI_MUL_DGELU || EPI == YTVLN_EPI_MUL_DRELU;
+            constexpr int NIT = 32 * IB / RPI, CH = 8;           // CH row accesses at a time: their global loads are in flight together
+            static_assert(NIT % CH == 0, "chunking");
+            for (int it0 = 0; it0 < NIT; it0 += CH) {
+                float4 t[CH], o[CH], a[CH];
+                if (vec) {
+                    if (beta != 0.f) {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            const int row = rbase + (it0 + c) * RPI + rsub;
+                            o[c] = (row < g.M && col < g.N) ? *reinterpret_cast<const float4*>(Cb + (int64_t)row * ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                    if constexpr (AUXLD) {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            const int row = rbase + (it0 + c) * RPI + rsub;
+                            a[c] = (row < g.M && col < g.N) ? *reinterpret_cast<const float4*>(g.aux + (int64_t)row * g.ldaux + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) t[c] = *reinterpret_cast<const float4*>(wlds + ((it0 + c) * RPI + rsub) * W + 4 * c4);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int row = rbase + (it0 + c) * RPI + rsub;
+                    if (row >= g.M || col >= g.N) continue;
+                    float v[4] = {t[c].x + bv[0], t[c].y + bv[1], t[c].z + bv[2], t[c].w + bv[3]};
+                    float* cp = Cb + (int64_t)row * ldc + col;
+                    float* xp = (EPI == YTVLN_EPI_GELU || AUXLD) ? g.aux + (int64_t)row * g.ldaux + col : nullptr;
+                    if (vec) {
+                        if constexpr (EPI == YTVLN_EPI_GELU) {
+                            if (g.aux) *reinterpret_cast<float4*>(xp) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = gelu_erf(v[u]);
+                        } else if constexpr (EPI == YTVLN_EPI_RELU) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+                        } else if constexpr (EPI == YTVLN_EPI_MUL_DGELU) {
+                            v[0] *= dgelu_erf(a[c].x); v[1] *= dgelu_erf(a[c].y); v[2] *= dgelu_erf(a[c].z); v[3] *= dgelu_erf(a[c].w);
+                        } else if constexpr (EPI == YTVLN_EPI_MUL_DRELU) {
+                            v[0] = a[c].x > 0.f ? v[0] : 0.f; v[1] = a[c].y > 0.f ? v[1] : 0.f; v[2] = a[c].z > 0.f ? v[2] : 0.f; v[3] = a[c].w > 0.f ? v[3] : 0.f;
+                        }
+                        if (beta != 0.f) { v[0] += beta * o[c].x; v[1] += beta * o[c].y; v[2] += beta * o[c].z; v[3] += beta * o[c].w; }
+                        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (col + u >= g.N) continue;
+                            float x = v[u];
+                            if constexpr (EPI == YTVLN_EPI_GELU) { if (g.aux) xp[u] = x; x = gelu_erf(x); }
+                            else if constexpr (EPI == YTVLN_EPI_RELU) x = fmaxf(x, 0.f);
+                            else if constexpr (EPI == YTVLN_EPI_MUL_DGELU) x *= dgelu_erf(xp[u]);
+                            else if constexpr (EPI == YTVLN_EPI_MUL_DRELU) x = xp[u] > 0.f ? x : 0.f;
+                            if (beta != 0.f) x += beta * cp[u];
+                            cp[u] = x;
+                        }
+                    }
+                }
+            }
+        };
+        switch (epi) {
+            case YTVLN_EPI_GELU: rows(std::integral_constant<int, YTVLN_EPI_GELU>{}); break;
+            case YTVLN_EPI_RELU: rows(std::integral_constant<int, YTVLN_EPI_RELU>{}); break;
+            case YTVLN_EPI_MUL_DGELU: rows(std::integral_constant<int, YTVLN_EPI_MUL_DGELU>{}); break;
+            case YTVLN_EPI_MUL_DRELU: rows(std::integral_constant<int, YTVLN_EPI_MUL_DRELU>{}); break;
+            default: rows(std::integral_constant<int, YTVLN_EPI_NONE>{}); break;
+        }
+    });
+}
+
+// ---- one wave per SIMD, software-pipelined main loop (round 3) -----------------------------------------------------------------------
+// What the round-3 probes measured (tools/lab/gen_mfma_lds_bench.py, tools/r3_gpu2-5.sh): while one wave of a SIMD
+// streams fp32 matrix instructions, the OTHER wave of that SIMD gets about one vector-memory / LDS / VALU instruction issued per matrix
+// instruction (64 cycles) -- a 35-instruction operand-load phase takes ~2100-2300 cycles beside a 2048-cycle matrix phase, which is what
+// holds gemm_dma_kernel (and the ping-pong form above) at 0.80-0.90 of the matrix peak.  The same instructions placed INSIDE the
+// matrix-issuing wave's own stream cost ~3 cycles per ds_read_b128 and ~11 per LDS-DMA piece.  Hence this form: four waves per workgroup,
+// one per SIMD, one workgroup per CU, up to 512 registers per lane; a wave's operand fragments are double-buffered in registers at
+// k-group granularity (4 k per group, 4 groups per 32-deep k-tile) and every fragment read / DMA issue is interleaved one behind a matrix
+// instruction (sched_group_barrier).  ONE workgroup barrier per k-tile, between k-groups 2 and 3:
+//   group 0..2 of tile t : matrix instructions of group g on F[g & 1]  ||  reads of group g + 1 -> F[(g + 1) & 1]
+//   before the barrier   : own DMA pieces of tile t + 1 retired (counted vmcnt), own reads of (t, group 3) retired (lgkmcnt(0))
+//   group 3 of tile t    : matrix instructions on F[1]  ||  DMA of tile t + NS into the slot of tile t (every wave is done reading it)
+//                                                       ||  reads of (t + 1, group 0) -> F[0]
+// so NS slots keep NS - 1 tiles of DMA in flight under a full tile of matrix work each.
+template <int BM, int BN, bool A_KC, bool B_KC, int NS>
+__global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
+    constexpr int NW = 4, KB = 32;
+    using TA = DmaTile<BM, A_KC, NW, KB>;
+    using TB = DmaTile<BN, B_KC, NW, KB>;
+    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;  // waves 2 (m) x 2 (n)
+    constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
+    constexpr int NPT = TA::NI + TB::NI;
+    constexpr int NMF = TM * TN * 4;                    // matrix instructions per k-group
+    constexpr int RDS = (A_KC ? TM : 4 * TM) + (B_KC ? TN : 4 * TN);   // LDS read instructions per k-group
+    static_assert(NS >= 2 && NS <= 4 && NS * STAGE * 4 <= 160 * 1024, "ring does not fit the LDS");
+    __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits, g.split_map);
+    const int m0 = tc.m * BM, n0 = tc.n * BN;
+    const int kbeg = tc.split * g.kchunk;
+    const int kend = min(g.Kloop, kbeg + g.kchunk);
+    const int nk = (kend - kbeg) / KB;
+    const bool tail_here = g.ktail && kend == g.Kloop;
+
+    const float* pa[TA::NI];
+    const float* pb[TB::NI];
+#pragma unroll
+    for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg, wave, lane, i, 0x7fffffff);
+#pragma unroll
+    for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg, wave, lane, i, 0x7fffffff);
+    const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool do_asum = !A_KC && g.asum != nullptr && tc.n == 0 && (wave & 1) == 0;
+    float asum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+
+    int st_in = 0;
+    auto issue = [&](int kt) {
+        float* As = smem + st_in * STAGE;
+        float* Bs = As + SA;
+        st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
+        if (tail_here && kbeg + (kt + 1) * KB > g.K) {
+#pragma unroll
+            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * KB, wave, lane, i, g.K - 1);
+#pragma unroll
+            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * KB, wave, lane, i, g.K - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < TA::NI; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
+            pa[i] += sa;
+        }
+#pragma unroll
+        for (int i = 0; i < TB::NI; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
+            pb[i] += sb;
+        }
+    };
+    auto retire = [&](int left) {         // wait for this wave's oldest outstanding tile; `left` younger tiles stay in flight
+        if (NS >= 4 && left >= 2) wait_vmcnt<2 * NPT>();
+        else if (NS >= 3 && left >= 1) wait_vmcnt<NPT>();
+        else wait_vmcnt<0>();
+    };
+
+    float4 fa[2][TM], fb[2][TN];
+    constexpr int NFR = TM + TN;                        // fragments per k-group
+    static_assert(NFR + NPT <= NMF, "more loads than matrix instructions in a k-group");
+    // (every register-array index below is a compile-time constant: a run-time index makes hipcc move the fragment arrays to scratch LDS)
+    // fragment R of k-group sg: the A fragments first, then the B fragments (one ds_read_b128, or four ds_read_b32 of a k-major image)
+    auto rd1 = [&](auto BUF, auto R, const float* __restrict__ As, const float* __restrict__ Bs, int sg) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value, r = decltype(R)::value;
+        if constexpr (r < TM) fa[buf][r] = TA::frag(As, wm0, r, l31, half, sg);
+        else fb[buf][r - TM] = TB::frag(Bs, wn0, r - TM, l31, half, sg);
+    };
+    auto mma1 = [&](auto BUF, auto K) __attribute__((always_inline)) {      // matrix instruction K of a group: k-major, accumulators alternate
+        constexpr int buf = decltype(BUF)::value, k = decltype(K)::value;
+        constexpr int c = k / (TM * TN), i = (k / TN) % TM, j = k % TN;
+        const float av = c == 0 ? fa[buf][i].x : c == 1 ? fa[buf][i].y : c == 2 ? fa[buf][i].z : fa[buf][i].w;
+        const float bv = c == 0 ? fb[buf][j].x : c == 1 ? fb[buf][j].y : c == 2 ? fb[buf][j].z : fb[buf][j].w;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+    };
+    // One k-group: matrix instruction k on F[CUR], then (pinned behind it) fragment k of the NEXT group into F[CUR ^ 1], then -- group 3 of a
+    // steady tile -- DMA piece k - NFR of tile kt + NS.  sched_barrier(0) after every step: the order IS the schedule.
+    auto group = [&](auto CUR, auto DMA_TAG, const float* __restrict__ As, const float* __restrict__ Bs, int sg_next, bool reads, float* Ad) __attribute__((always_inline)) {
+        constexpr int cur = decltype(CUR)::value;
+        constexpr bool DMA = decltype(DMA_TAG)::value;
+        if constexpr (!A_KC) {
+            if (do_asum) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asum[i] += (fa[cur][i].x + fa[cur][i].y) + (fa[cur][i].z + fa[cur][i].w);
+            }
+        }
+        static_for<NMF>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            mma1(CUR, K);
+            if constexpr (k < NFR) {
+                if (reads && !(g.probe & 2)) rd1(std::integral_constant<int, cur ^ 1>{}, K, As, Bs, sg_next);
+            }
+            if constexpr (DMA && k >= NFR && k - NFR < TA::NI) {
+                constexpr int d = k - NFR;
+                if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[d], (lds_ptr_t)(Ad + (wave * TA::NI + d) * 256), 16, 0, 0);
+                pa[d] += sa;
+            } else if constexpr (DMA && k >= NFR + TA::NI && k - NFR < NPT) {
+                constexpr int e = k - NFR - TA::NI;
+                if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[e], (lds_ptr_t)(Ad + SA + (wave * TB::NI + e) * 256), 16, 0, 0);
+                pb[e] += sb;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_c1 = 0;
+    if (g.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    const int npro = min(nk, NS);
+    for (int t = 0; t < npro; ++t) issue(t);
+    retire(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    if (g.dbg) { dbg_t1 = __builtin_amdgcn_s_memrealtime(); dbg_c1 = __builtin_amdgcn_s_memtime(); }
+    static_for<NFR>([&](auto R) __attribute__((always_inline)) { rd1(I0{}, R, smem, smem + SA, 0); });
+
+    int st_out = 0;
+    // STEADY tiles (every tile but the last NS + 1) have no K tail, always issue tile kt + NS and always read tile kt + 1: their body is
+    // ONE basic block, so the DMA issues and the next tile's first reads sit between the matrix instructions of k-group 3.
+    auto tile = [&](auto steady_tag, int kt) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const float* As = smem + st_out * STAGE;
+        const float* Bs = As + SA;
+        st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
+        const float* An = smem + st_out * STAGE;      // next tile's slot
+        group(I0{}, std::false_type{}, As, Bs, 1, true, nullptr);
+        group(I1{}, std::false_type{}, As, Bs, 2, true, nullptr);
+        group(I0{}, std::false_type{}, As, Bs, 3, true, nullptr);
+        if constexpr (STEADY) wait_vmcnt<(NS - 2) * NPT>();       // my pieces of tile kt + 1; tiles kt + 2 .. kt + NS - 1 stay in flight
+        else if (kt + 1 < nk) retire(min(NS - 2, nk - 2 - kt));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of (kt, group 3): the slot may be overwritten behind the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STEADY) {
+            float* Ad = smem + st_in * STAGE;
+            st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
+            group(I1{}, std::true_type{}, An, An + SA, 0, true, Ad);
+        } else {
+            if (kt + NS < nk) issue(kt + NS);
+            group(I1{}, std::false_type{}, An, An + SA, 0, kt + 1 < nk, nullptr);
+        }
+    };
+    int kt = 0;
+    for (; kt < nk - NS - 1; ++kt) tile(std::true_type{}, kt);
+    for (; kt < nk; ++kt) tile(std::false_type{}, kt);
+    if constexpr (!A_KC) {
+        if (do_asum) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = asum[i] + __shfl_xor(asum[i], 32, 64);
+                const int row = m0 + wm0 + 32 * i + l31;
+                if (half == 0 && row < g.M) {
+                    if (g.splits > 1) g.asum_ws[(int64_t)tc.split * g.M + row] = v;
+                    else g.asum[row] = v;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();        // every wave is done reading the ring (and no DMA is in flight): it becomes the epilogue's staging space
+    unsigned long long dbg_t2 = 0, dbg_c2 = 0;
+    if (g.dbg) { dbg_t2 = __builtin_amdgcn_s_memrealtime(); dbg_c2 = __builtin_amdgcn_s_memtime(); }
+    static_assert(4 * 64 * 32 * TN * 4 <= NS * STAGE * 4, "epilogue staging does not fit the ring");
+    epilogue_lds<TM, TN>(g, acc, smem + wave * (64 * 32 * TN), m0 + wm0, n0 + wn0, lane, tc.split);
+    if (g.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+            d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = t3; d[4] = dbg_c2 - dbg_c1;
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            d[5] = ((unsigned long long)xcc << 32) | hwid; d[6] = nk;
+        }
+    }
 }
 
 // The three-term (X3) kernels are instantiated in their own translation unit -- gemm_x3.hip includes this file with YT_GEMM_X3_TU
 // defined -- so that the two halves of the GEMM code compile in parallel.  128x128 tiles run as 4 waves of 64x64 there (two workgroups
 // per CU: 7.3 instead of 11 VALU ops per MFMA, 154 -> 166 TFLOP/s on 16128x1024x1024 forced onto that tile).
 void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s);
+// The one-wave-per-SIMD kernels likewise (gemm_sw.hip, YT_GEMM_SW_TU).  Returns false when no instantiation exists for the tile.
+bool launch_sw(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s);
 
-#ifdef YT_GEMM_X3_TU
+#if defined(YT_GEMM_SW_TU)
+template <int BM, int BN, int NS>
+static void launch_sw_tile(const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
+    const dim3 gr(grid), blk(256);
+    if (!transA && transB) hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, true, true, NS>), gr, blk, 0, s, g);
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, true, false, NS>), gr, blk, 0, s, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, false, false, NS>), gr, blk, 0, s, g);
+    else hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, false, true, NS>), gr, blk, 0, s, g);
+}
+bool launch_sw(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
+    if (bm == 128 && bn == 128) { launch_sw_tile<128, 128, 3>(g, transA, transB, grid, s); return true; }
+    if (bm == 256 && bn == 128) { launch_sw_tile<256, 128, 3>(g, transA, transB, grid, s); return true; }
+    if (bm == 256 && bn == 256) { launch_sw_tile<256, 256, 2>(g, transA, transB, grid, s); return true; }
+    return false;
+}
+}  // namespace ytvln
+#elif defined(YT_GEMM_X3_TU)
 template <int BM, int BN, int NW, int WPS>
 static void launch_x3_tile(const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
     const dim3 gr(grid), blk(NW * 64);
@@ -912,6 +1272,9 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
+        // opt-in (YTVLN_GEMM_SW=1): the one-wave-per-SIMD software-pipelined kernels (gemm_sw_kernel) for the 128x128 / 256x128 / 256x256 tiles
+        static const int sw = getenv("YTVLN_GEMM_SW") ? atoi(getenv("YTVLN_GEMM_SW")) : 0;
+        if (sw && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
         if constexpr (BM == 256 && BN == 256) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
@@ -1139,6 +1502,16 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     static const int split_map = getenv("YTVLN_GEMM_SPLIT_MAP") ? atoi(getenv("YTVLN_GEMM_SPLIT_MAP")) : 1;
     g.split_map = split_map;
     g.asum = nullptr; g.asum_ws = nullptr;
+    static const int probe = getenv("YTVLN_GEMM_PROBE") ? atoi(getenv("YTVLN_GEMM_PROBE")) : 0;
+    g.probe = probe;
+    static const int dbg_on = getenv("YTVLN_GEMM_DBG") ? atoi(getenv("YTVLN_GEMM_DBG")) : 0;
+    static unsigned long long* dbg_buf = nullptr;
+    static int dbg_calls = 0;
+    g.dbg = nullptr;
+    if (dbg_on) {
+        if (!dbg_buf) hipMalloc(&dbg_buf, 8192 * 8 * sizeof(unsigned long long));
+        g.dbg = dbg_buf;
+    }
     // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
     // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
     // B's k rows are clamped -- B must be [K,N]), and an M-contiguous A may have M % 4 != 0.
@@ -1210,6 +1583,27 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
         else launch_tile<64, 64>(g, transA, transB, s);
     }
     YT_LAUNCH_CHECK("gemm_f32");
+    if (dbg_on && ++dbg_calls == dbg_on) {          // debugging aid: dump the clocks of call number YTVLN_GEMM_DBG
+        hipDeviceSynchronize();
+        const int nb = g.ntiles * g.splits;
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t3 = 0;
+        double loop_us = 0, cyc = 0, pro = 0, epi = 0;
+        for (int b = 0; b < nb; ++b) { t0 = std::min(t0, h[(size_t)b * 8]); t3 = std::max(t3, h[(size_t)b * 8 + 3]); }
+        for (int b = 0; b < nb; ++b) {
+            const unsigned long long* d = &h[(size_t)b * 8];
+            loop_us += (d[2] - d[1]) * 0.01 / nb; cyc += (double)d[4] / nb; pro += (d[1] - d[0]) * 0.01 / nb; epi += (d[3] - d[2]) * 0.01 / nb;
+        }
+        const double mfma_cyc = 2.0 * (double)std::min(M, g.tiles_m * (M + g.tiles_m - 1) / g.tiles_m) * 0 + 0;
+        (void)mfma_cyc;
+        const double tile_cyc = (double)(M > 0 ? 1 : 1) * 0;
+        (void)tile_cyc;
+        const int bm = (int)cdiv(M, g.tiles_m), bn = (int)cdiv(N, g.tiles_n);       // (approximate tile extents)
+        const double ideal = (double)h[6] * 32.0 * ((bm + 31) / 32 * 32) * ((bn + 31) / 32 * 32) * 2.0 / 256.0;   // matrix-pipe cycles of one workgroup's loop
+        fprintf(stderr, "gemmdbg %d x %d x %d tA%d tB%d: %d workgroups, kernel %.1f us, prologue %.1f, loop %.1f (%.0f cycles = %.3f of the matrix pipe, clock %.3f GHz), epilogue %.1f us\n",
+                M, N, K, transA, transB, nb, (t3 - t0) * 0.01, pro, loop_us, cyc, ideal / cyc, cyc / loop_us * 1e-3, epi);
+    }
     return 0;
 }
 
@@ -1295,7 +1689,7 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
     g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr; g.x3 = 0;
-    g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1;
+    g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1; g.probe = 0; g.dbg = nullptr;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
     bool big_split = false;
     int want = plan_splits_bf16_any(M, N, K / 2, epilogue, &big_split);
