@@ -148,6 +148,63 @@ def effective_cores() -> int:
     return max(1, n)
 
 
+class FamilyTimer:
+    """Brackets the attention / LayerNorm / AdamW entry points of the C ABI with HIP events (eager pass only) and keeps the algorithmic work of
+    each call, so that the bench line carries one roofline entry per kernel family (attention by USEFUL matrix FLOPs -- no recompute, no
+    padding --, LayerNorm and AdamW by algorithmic bytes against the 8 TB/s HBM figure).  GEMM launches have their own timer (GemmTimer)."""
+    FAMILIES = (("ytvln_attn_", "attention"), ("ytvln_ln_", "layernorm"), ("ytvln_adamw", "adamw"))
+
+    def __init__(self):
+        self.records = []
+        self.on = False
+
+    def install(self):
+        from ytvln import ops
+        inner = ops.call
+        timer = self
+
+        def timed(name, *args):
+            fam = None
+            if timer.on:
+                for prefix, f in timer.FAMILIES:
+                    if name.startswith(prefix):
+                        fam = f
+                        break
+            if fam is None:
+                return inner(name, *args)
+            work = 0.0
+            if fam == "layernorm":           # (.., rows, H, ..): 12 B read/written + 4 B saved per element forward, 20 B backward
+                rows, H = int(args[8]), int(args[9])
+                work = rows * H * (20.0 if "bwd" in name else 16.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = inner(name, *args)
+            e1.record()
+            timer.records.append((fam, e0, e1, work))
+            return r
+
+        ops.call = timed
+
+    def summary(self):
+        out = {}
+        for fam, e0, e1, work in self.records:
+            d = out.setdefault(fam, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1)
+            d[1] += work
+            d[2] += 1
+        return out
+
+
+def attention_useful_flops(cfg, N, T, R):
+    """Useful matrix FLOPs of all attention sites of one training step: 4 Tq Tk (heads x d) per (pair) forward + 8 backward (dV, dP, dQ, dK),
+    i.e. without the backward's score recompute and without tile padding (vilbert/vilbert.py:276-307, 413-440)."""
+    f = 12.0 * N
+    text = cfg.num_hidden_layers * T * T * cfg.hidden_size
+    image = cfg.v_num_hidden_layers * R * R * cfg.v_hidden_size
+    co = len(cfg.v_biattention_id) * 2 * T * R * cfg.bi_hidden_size
+    return f * (text + image + co)
+
+
 def cpu_baseline(workload, budget_s: float = 45.0):
     """Oracle (port of the reference's PyTorch CPU path) on the host cores: bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -180,6 +237,22 @@ def cpu_baseline(workload, budget_s: float = 45.0):
                       f"after {1 if len(times) > 1 else 0} warm-up ({med:.2f} s/step)"}
 
 
+class stdout_to_stderr:
+    """File-descriptor level: native libraries (gloo's connection notice, RCCL's version banner under NCCL_DEBUG=INFO) print to fd 1 while
+    they initialise; the bench's stdout carries exactly ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def self_launch(n: int):
     """`python bench.py --gpus N` without a launcher: re-exec as N ranks of ONE node under torch.distributed.run -- the command the
     reference's README uses for its own multi-GPU runs (README.md:98-100, `python -m torch.distributed.launch --nproc_per_node ...`)."""
@@ -195,10 +268,26 @@ def self_launch(n: int):
     os.execv(sys.executable, cmd)
 
 
+_REAL_STDOUT = None
+
+
+def emit(line: str):
+    """The ONE JSON line, on the process's original stdout (see main: fd 1 itself points at stderr while the bench runs)."""
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a.gpus)                        # does not return
+    # Native libraries print to fd 1 whenever they like (gloo's connection notice at start-up, RCCL's version banner under
+    # NCCL_DEBUG=INFO when the communicator is torn down): keep the original stdout for the JSON line and point fd 1 at stderr.
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -214,6 +303,12 @@ def main():
     from ytvln import distributed as D
     collective = D.default_collective()
     dp_wrap = world > 1 or a.dp_selftest
+    rccl_log = None
+    if dp_wrap and os.environ.get("YTVLN_BENCH_RCCL_INFO", "1") != "0" and "NCCL_DEBUG" not in os.environ:
+        # the N > 1 line explains itself: RCCL's own choice of algorithm / protocol for the gradient all-reduce, read back from its log
+        # (a FILE: the bench's stdout carries exactly one JSON line)
+        rccl_log = f"/tmp/ytvln_rccl_{os.getpid()}.log"
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,TUNING,GRAPH", NCCL_DEBUG_FILE=rccl_log)
     if dp_wrap:
         # Data plane: the C ABI's own RCCL communicator (ytvln_rccl_*), torch.distributed = env:// rendezvous + gloo control plane.
         # YTVLN_DP_COLLECTIVE=torch runs the exchange through torch.distributed instead ("nccl" = RCCL on ROCm).
@@ -228,7 +323,8 @@ def main():
         if world == 1 and "MASTER_PORT" not in os.environ:
             import socket
             sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
-        D.init_distributed(backend="nccl" if (collective == "torch" and world <= ndev) else "gloo", force=True)
+        with stdout_to_stderr():
+            D.init_distributed(backend="nccl" if (collective == "torch" and world <= ndev) else "gloo", force=True)
 
     from ytvln import ops as yt_ops
     from ytvln import synth, utils_init
@@ -256,7 +352,9 @@ def main():
                                             finetune_heading=not args.pretrain), dev)
     runner = model
     if dp_wrap:
-        runner = DataParallel(model, broadcast=True, collective=collective, always_exchange=a.dp_selftest)
+        with stdout_to_stderr():
+            runner = DataParallel(model, broadcast=True, collective=collective, always_exchange=a.dp_selftest)
+            torch.cuda.synchronize()
     opt, sched, _, _ = get_optimization(args, model, a.steps + a.warmup + 1, None)
     if dp_wrap:
         runner.attach(opt)
@@ -270,8 +368,10 @@ def main():
         return float(t.item())
 
     timer = GemmTimer()
+    ftimer = FamilyTimer()
     if not a.no_kernel_timing:
         timer.install()
+        ftimer.install()
 
     infer = a.workload.startswith("infer")
     if infer:
@@ -344,7 +444,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = not use_graph             # graph replays cannot bracket single kernels: see the eager pass below
+    timer.on = ftimer.on = not use_graph             # graph replays cannot bracket single kernels: see the eager pass below
     if a.h2d != "off":
         # PCIe-inclusive variant: the step consumes `batch` (static device tensors); a pinned host copy is re-uploaded every step.
         host = [t.cpu().pin_memory() if torch.is_tensor(t) else t for t in batch]
@@ -398,15 +498,17 @@ def main():
             step(a.warmup + i)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
+    c0 = time.thread_time()
     for i in range(a.steps):
         loss, _ = step(a.warmup + i)
-    host_enqueue = time.perf_counter() - t0          # host time to enqueue the timed steps (before the device drains)
+    host_enqueue = time.perf_counter() - t0          # wall time until the last step is enqueued: INCLUDES waiting for room in the stream's queue
+    host_cpu = time.thread_time() - c0               # CPU time this thread spent enqueueing: what N ranks on one host really compete for
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.on = False
+    timer.on = ftimer.on = False
     elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)
     final_loss = float(loss)
     assert np.isfinite(final_loss), "training diverged"
@@ -417,6 +519,69 @@ def main():
         with torch.no_grad():
             chk = float(sum(p.detach().double().sum() for p in model.parameters()))
         replica_spread = control_reduce(chk, dist.ReduceOp.MAX) - control_reduce(chk, dist.ReduceOp.MIN)
+    dp_diag = None
+    if dp_wrap and not infer:
+        dp_diag = {}
+        try:
+            flat = opt.flat_grad()
+            nbytes = flat.numel() * flat.element_size()
+            # (a) the exchange alone: the whole gradient arena, as the step issues it, 3 repetitions between events on the current stream
+            reps = 3
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cap = max(1, (256 << 20) // flat.element_size())
+            slices = [(lo, min(lo + cap, flat.numel())) for lo in range(0, flat.numel(), cap)]
+            e0.record()
+            for _ in range(reps):
+                if runner.comm is not None:
+                    runner.comm.all_reduce_slices(flat, slices)
+                else:
+                    for lo, hi in slices:
+                        dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = control_reduce(e0.elapsed_time(e1) / reps, dist.ReduceOp.MAX)
+            flat.zero_()
+            dp_diag["allreduce_bytes"] = nbytes
+            dp_diag["allreduce_alone_ms"] = round(ar_ms, 3)
+            dp_diag["allreduce_alg_gbps"] = round(nbytes / (ar_ms * 1e-3) / 1e9, 1)
+            dp_diag["allreduce_bus_gbps"] = round(nbytes / (ar_ms * 1e-3) / 1e9 * (2.0 * (world - 1) / world if world > 1 else 1.0), 1)
+            # (b) how much of it the step exposes: two more (untimed) steps with events around the wait for the communication stream
+            if use_graph:
+                gs.profile = True
+                exp = []
+                for i in range(2):
+                    step(a.warmup + a.steps + 10 + i)
+                    x = gs.exposed_exchange_ms()
+                    if x is not None:
+                        exp.append(x)
+                gs.profile = False
+                if exp:
+                    dp_diag["exchange_exposed_ms"] = round(control_reduce(sum(exp) / len(exp), dist.ReduceOp.MAX), 3)
+                    dp_diag["exchange_form"] = gs.mode
+        except Exception as e:       # diagnostics never take the measurement down
+            dp_diag["error"] = f"{type(e).__name__}: {e}"
+        if rccl_log and os.path.exists(rccl_log):
+            import re
+            algo = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+            proto = {0: "LL", 1: "LL128", 2: "Simple"}
+            seen, chans, transports = [], None, set()
+            for line in open(rccl_log, errors="replace"):
+                m = re.search(r"(\d+) Bytes -> Algo (\d+) proto (\d+)", line)
+                if m:
+                    t = (int(m.group(1)), algo.get(int(m.group(2)), m.group(2)), proto.get(int(m.group(3)), m.group(3)))
+                    if t not in seen:
+                        seen.append(t)
+                m = re.search(r"(\d+) coll channels", line)
+                if m:
+                    chans = int(m.group(1))
+                m = re.search(r"via (P2P/\w+|SHM\S*|NET/\S+)", line)
+                if m:
+                    transports.add(m.group(1))
+            dp_diag["rccl"] = {"choices": [{"bytes": b, "algo": al, "proto": pr} for b, al, pr in seen[-6:]], "coll_channels": chans,
+                               "transports": sorted(transports), "log": rccl_log}
     if infer:
         execution = "eager launches, eval mode, forward only"
     roofline_note = "HIP events around every GEMM launch during the timed steps"
@@ -424,11 +589,11 @@ def main():
         n_prof = min(a.steps, 3)
         eager_step(a.warmup + a.steps)        # untimed: eager launches allocate outside the graph's memory pool the first time
         torch.cuda.synchronize()
-        timer.on = True
+        timer.on = ftimer.on = True
         for i in range(n_prof):
             eager_step(a.warmup + a.steps + 1 + i)
         torch.cuda.synchronize()
-        timer.on = False
+        timer.on = ftimer.on = False
         roofline_note = f"HIP events around every GEMM launch during {n_prof} eager steps run right after the timed graph replays"
 
     pairs_per_step = bs * K * world
@@ -447,11 +612,15 @@ def main():
                    "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}",
                    "execution": execution, "heads": "loss-aware rows (extension)" if a.loss_aware_heads else "all rows (reference)"},
         "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
-        "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / a.steps, 2),
+        "host_enqueue_ms_per_step": round(1000.0 * control_reduce(host_enqueue, dist.ReduceOp.MAX) / a.steps, 2),
+        "host_cpu_ms_per_step": round(1000.0 * control_reduce(host_cpu, dist.ReduceOp.MAX) / a.steps, 2),
+        "host_cores_available": effective_cores(),
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
     }
     if replica_spread is not None:
         out["config"]["replica_checksum_spread"] = replica_spread
+    if dp_diag is not None:
+        out["data_parallel"] = dp_diag
     if dp_wrap and use_graph and getattr(gs, "mode", "") == "phased":
         # MB of gradients per exchange group, in the order they go out (the last one is the exposed tail)
         out["config"]["exchange_groups_mb"] = [round(4e-6 * sum(hi - lo for lo, hi in g), 1) for g in gs._group_slices]
@@ -487,8 +656,35 @@ def main():
                 pass
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": traffic, "traffic_source": traffic_note, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
+                           "traffic": traffic, "traffic_static": True, "traffic_source": traffic_note, "launches": n, "avg_launch_us": round(1000.0 * ms / n, 2),
                            "avg_launch_gflop": round(flop / n / 1e9, 3), "measured": roofline_note}
+        # one entry per kernel family, same eager pass: enough to recompute every fraction from this line alone
+        nsteps_prof = max(1, (n_prof if use_graph else a.steps))
+        fams = {"gemm": {"bound": "mfma", "ms_per_step": round(ms / nsteps_prof, 3), "launches_per_step": round(n / nsteps_prof, 1),
+                         "work_per_step": round(flop / nsteps_prof / 1e12, 4), "work_unit": "TFLOP (2MNK)", "achieved": round(ach, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4)}}
+        fsum = ftimer.summary()
+        if "attention" in fsum and not infer:
+            fms, _, fn = fsum["attention"]
+            useful = attention_useful_flops(cfg, bs * K, T, frames * boxes) * nsteps_prof
+            apeak = PEAK_BF16_MFMA_TFLOPS if a.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+            fams["attention"] = {"bound": "mfma", "ms_per_step": round(fms / nsteps_prof, 3), "launches_per_step": round(fn / nsteps_prof, 1),
+                                 "work_per_step": round(useful / nsteps_prof / 1e12, 4), "work_unit": "TFLOP useful (12 Tq Tk hd per pair and site: no recompute, no padding)",
+                                 "achieved": round(useful / (fms * 1e-3) / 1e12, 2), "peak": apeak, "unit": "TFLOP/s",
+                                 "frac": round(useful / (fms * 1e-3) / 1e12 / apeak, 4)}
+        if "layernorm" in fsum:
+            fms, fbytes, fn = fsum["layernorm"]
+            fams["layernorm"] = {"bound": "hbm", "ms_per_step": round(fms / nsteps_prof, 3), "launches_per_step": round(fn / nsteps_prof, 1),
+                                 "work_per_step": round(fbytes / nsteps_prof / 1e9, 3), "work_unit": "GB algorithmic (16 B/element forward incl. the saved sum, 20 B backward)",
+                                 "achieved": round(fbytes / (fms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fbytes / (fms * 1e-3) / 1e9 / 8000.0, 4)}
+        if "adamw" in fsum:
+            fms, _, fn = fsum["adamw"]
+            fl = opt.flat_grad()
+            abytes = 28.0 * (fl.numel() if fl is not None else n_params) * nsteps_prof
+            fams["adamw"] = {"bound": "hbm", "ms_per_step": round(fms / nsteps_prof, 3), "launches_per_step": round(fn / nsteps_prof, 1),
+                             "work_per_step": round(abytes / nsteps_prof / 1e9, 3), "work_unit": "GB algorithmic (28 B per parameter that has a gradient)",
+                             "achieved": round(abytes / (fms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(abytes / (fms * 1e-3) / 1e9 / 8000.0, 4)}
+        out["roofline"]["families"] = fams
         if a.kernel_table and rank == 0:
             rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
             print(f"{'M':>7} {'N':>6} {'K':>6} tA tB {'calls':>6} {'ms':>9} {'TF/s':>7}", file=sys.stderr)
@@ -562,7 +758,7 @@ def main():
     if rank == 0 and world == 1 and not dp_wrap and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.workload)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dp_wrap:
         runner.close()
         if dist.is_initialized():

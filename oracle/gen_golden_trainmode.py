@@ -9,8 +9,8 @@ g14 -- train-mode (dropout ON) agreement "in distribution" (SURVEY.md H1).  The 
        (`utils/utils_init.py:199-239` loop body), 20 optimizer steps, N_SEEDS mask seeds (`torch.manual_seed(seed)` before the model is
        put in train mode).  Stored: every loss of every seed and step [seeds, steps, 5] (total, ranking, traj, vision, language) -- the GPU
        test compares the mean over ITS seeds with the mean over these, in units of the reference's own standard deviation.
-g15 -- the same recipe with p = 0 (no `opt_mask` hole, all four heads): a FINITE 20-step loss trajectory + the parameters after step 3
-       and step 20 (g0's multi-step trajectory is NaN in the reference itself because of its `opt_mask` hole).
+g15 -- the same recipe with p = 0 (no `opt_mask` hole, all four heads): a FINITE 20-step loss trajectory + per-tensor norms / sums of the
+       parameters after step 3 and step 20 (g0's multi-step trajectory is NaN in the reference itself because of its `opt_mask` hole).
 The oracle restatement runs beside the reference for g15 and the script aborts on disagreement.
 """
 from __future__ import annotations
@@ -80,8 +80,8 @@ def g15(R):
     batch = synth.to_torch(synth.make_batch(**RECIPE))
     out = {}
     rows3, model3, _ = _run(R, rcfg, args, W, batch, 0, 3, 0.0)
-    for n, p in model3.named_parameters():
-        out["after3/" + n] = G.np_(p)
+    out["post3_norm"] = np.array([p.double().norm().item() for _, p in model3.named_parameters()])
+    out["post3_sum"] = np.array([p.double().sum().item() for _, p in model3.named_parameters()])
     rows, model, sched = _run(R, rcfg, args, W, batch, 0, STEPS, 0.0)
     assert np.isfinite(rows).all() and np.array_equal(rows[:3], rows3)
     # the oracle beside it

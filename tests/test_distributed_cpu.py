@@ -1,4 +1,4 @@
-"""CPU, world_size = 2 over gloo: the data-parallel gradient exchange (ytvln/distributed.py) is correct by construction.
+"""CPU, world_size = 2 (and 8) over gloo: the data-parallel gradient exchange (ytvln/distributed.py) is correct by construction.
 
 The bucket reducer and the DataParallel wrapper are device-agnostic; here they are driven by a small CPU network whose
 parameters / gradients are views into flat arenas exactly as ytvln.optimization.AdamW lays them out on the GPU."""
@@ -69,12 +69,12 @@ def worker(rank, world, port, q):
     w0 = [p.detach().clone() for p in net.parameters()]
     gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
     dist.all_gather(gathered, w0[0])
-    assert torch.equal(gathered[0], gathered[1]), "parameters must be identical after wrapping"
+    assert all(torch.equal(gathered[0], g_) for g_ in gathered), "parameters must be identical after wrapping"
     opt = ArenaSGD(net.parameters(), lr=0.1)
     dp.attach(opt)
-    assert opt.grad_scale == 0.5
+    assert opt.grad_scale == 1.0 / world
     g = torch.Generator().manual_seed(7)
-    X = torch.randn(2, 3, 5, 6, generator=g)           # [step, rank, batch, features]
+    X = torch.randn(2, world, 5, 6, generator=g)           # [step, rank, batch, features]
     losses = []
     for step in range(3):                              # step 0 builds the arena (non-overlapped), steps 1-2 use the hooks
         loss = dp(X[step % 2, rank]).pow(2).mean()
@@ -91,20 +91,22 @@ def worker(rank, world, port, q):
     chk = torch.cat([o.reshape(-1) for o in out])
     both = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(both, chk)
-    assert torch.equal(both[0], both[1])
+    assert all(torch.equal(both[0], b_) for b_ in both)
     dist.destroy_process_group()
 
 
-def test_data_parallel_equals_single_process_average():
+@pytest.mark.parametrize("world", [2, 8])
+def test_data_parallel_equals_single_process_average(world):
+    """world 8 = the node size of BASELINE configs[2]: buckets, the rank-0 broadcast, 1/world averaging and bit-identical replicas."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    w0, out, X = q.get(timeout=120)
+    w0, out, X = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     # single-process restatement: average of the two ranks' gradients each step (DDP semantics)
     net = Net()
@@ -114,14 +116,14 @@ def test_data_parallel_equals_single_process_average():
     X = torch.from_numpy(X)
     for step in range(3):
         grads = []
-        for rank in range(2):
+        for rank in range(world):
             net.zero_grad()
             net(X[step % 2, rank]).pow(2).mean().backward()
             grads.append([None if p.grad is None else p.grad.clone() for p in net.parameters()])
         with torch.no_grad():
-            for p, g0, g1 in zip(net.parameters(), *grads):
-                if g0 is not None:
-                    p.add_((g0 + g1) * 0.5, alpha=-0.1)
+            for p, *gs in zip(net.parameters(), *grads):
+                if gs[0] is not None:
+                    p.add_(sum(gs) / world, alpha=-0.1)
     for p, o in zip(net.parameters(), out):
         assert torch.allclose(p.detach(), torch.from_numpy(o), atol=1e-6, rtol=1e-5)
 
@@ -220,7 +222,51 @@ def test_rccl_binding_resolves_pytorchs_librccl_without_a_gpu():
     assert default_collective() == ("rccl" if torch.cuda.is_available() else "torch")
 
 
-def test_bench_self_launch_command(monkeypatch):
+def digest_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ytvln import distributed as D
+    D.init_distributed(backend="gloo")
+
+    class Opt:
+        def flat_grad(self):
+            return torch.zeros(1000)
+    gs = object.__new__(D.GraphedTrainStep)             # (capturing needs a device; the agreement check does not)
+    gs.mode, gs.world, gs.group, gs.opt = "phased", world, None, Opt()
+    gs._slices = [(0, 1000)]
+    gs._group_slices = [[(0, 600)], [(600, 1000)]]
+    gs.verify_layout_across_ranks()                      # identical on every rank: passes
+    same = gs.layout_digest()
+    if rank == world - 1:
+        gs._group_slices = [[(0, 500)], [(500, 1000)]]   # one rank observed another phase boundary
+    raised = False
+    try:
+        gs.verify_layout_across_ranks()
+    except RuntimeError as e:
+        raised = "different gradient-exchange layouts" in str(e)
+    q.put((rank, raised, same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_refuses_mismatched_exchange_layouts():
+    """the phased step derives its exchange groups from what each rank observed during capture; ranks that disagree must get an
+    error on EVERY rank before the first grouped all-reduce, not a hang inside RCCL."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=digest_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(raised for _, raised, _ in res)
+    assert res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_self_launch_command(monkeypatch, n):
     """`python bench.py --gpus N` without WORLD_SIZE re-execs under torch.distributed.run on 127.0.0.1 (README.md:98-100 counterpart)."""
     import importlib
     import sys
@@ -229,11 +275,11 @@ def test_bench_self_launch_command(monkeypatch):
     bench = importlib.import_module("bench")
     seen = {}
     monkeypatch.setattr(bench.os, "execv", lambda exe, argv: seen.update(exe=exe, argv=argv) or (_ for _ in ()).throw(SystemExit(0)))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit):
         bench.main()
     argv = seen["argv"]
-    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in argv
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and f"--nproc-per-node={n}" in argv
     assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
-    assert argv[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and argv[-7].endswith("bench.py")
+    assert argv[-6:] == ["--gpus", str(n), "--steps", "2", "--warmup", "1"] and argv[-7].endswith("bench.py")

@@ -158,3 +158,27 @@ def test_g7_masking_restatement_matches_reference():
     # the fixture exercises every branch
     p = t("p_tok") * t("mask").float()
     assert int(((p >= 0.85) & (p < 0.97)).sum()) > 0 and int(((p >= 0.97) & (p < 0.985)).sum()) > 0 and int((p >= 0.985).sum()) > 0
+
+
+def test_g15_oracle_follows_the_reference_trajectory():
+    """The finite multi-step golden (oracle/gen_golden_trainmode.py g15): the oracle's first six AdamW steps on the tiny config reproduce the
+    reference's loss trajectory, and g14's seed statistics are self-consistent (finite, mean / std recomputable from the stored runs)."""
+    g = gold("g15_tiny_traj20.npz")
+    cfg = O.RefConfig(**cfg_dict("tiny_2_2_1.json", **ZERO_DROP))
+    fl = flags(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    import json, os
+    from conftest import GOLD
+    shapes = json.load(open(os.path.join(GOLD, "state_dict_schema.json")))["Lily/tiny_2_2_1.json"]["shapes"]
+    W = synth.make_weights({k: tuple(v) for k, v in shapes.items()}, int(g["w_seed"]))
+    batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=16, frames=2, boxes=4, seed=31, ignore_rank_frac=0.0))
+    S, st = state(W), O.AdamWState()
+    warm, tot = O.schedule_totals(int(g["total_steps"]), 1, 1)
+    assert np.isfinite(g["losses"]).all()
+    for step in range(6):
+        loss, _, _, _ = O.train_step(S, cfg, fl, batch, st, float(g["lr"]) * O.warmup_linear(step, warm, tot))
+        assert abs(float(loss) - g["losses"][step, 0]) <= 2e-5 * (step + 1), (step, float(loss), g["losses"][step, 0])
+    s = gold("g14_trainmode_stats.npz")
+    runs = s["losses"].astype(np.float64)
+    assert runs.shape == (int(s["n_seeds"]), int(s["steps"]), 5) and np.isfinite(runs).all()
+    assert np.allclose(runs.mean(0), s["mean"], atol=1e-5) and np.allclose(runs.std(0, ddof=1), s["std"], atol=1e-5)
+    assert (s["std"][:, 0] > 0).all()          # dropout really was on: the seeds differ

@@ -76,6 +76,8 @@ def _worker(case, port, q):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
         collective, mode = case.split(":")
+        metrics = mode.endswith("+metrics")       # the reference's default: local_rank != -1 and --skip_all_reduce off -> logged metrics are all-reduced
+        mode = mode.replace("+metrics", "")
         if mode == "phased3":           # explicit cut list: a text-only cut below the co-attention layer, the layer itself, an image-only cut above
             os.environ["YTVLN_DP_CUTS"] = "t0,c0,v1"
             mode = "phased"
@@ -83,6 +85,8 @@ def _worker(case, port, q):
         assert dist.get_world_size() == 1 and dist.get_backend() == ("nccl" if collective == "torch" else "gloo")
         model, args = _build(dev)
         args.learning_rate = 1e-3
+        if metrics:
+            args.local_rank, args.skip_all_reduce = 0, False
         dp = D.DataParallel(model, bucket_bytes=64 << 10, collective=collective, always_exchange=True)
         assert (dp.comm is not None) == (collective == "rccl")
         info = {}
@@ -114,6 +118,12 @@ def _worker(case, port, q):
             if mode == "phased":        # the cut points are gone once the phases are recorded: an eager step sees the uncut graph
                 assert all(not m.cut_after for m in model.modules() if hasattr(m, "cut_after"))
         torch.cuda.synchronize()
+        if metrics:       # the metric reductions ride on the RCCL data plane (stream-ordered, capturable), not on the gloo control plane
+            red = {"loss": {}, "accuracy": {}}
+            out = dp(*U.get_model_input(batch, True))
+            l = U.compute_metrics_independent(batch, out, "ranking", args, None, red, all_options=True)
+            assert torch.allclose(red["loss"]["ranking"], l.detach()) and red["loss"]["ranking"].is_cuda
+            assert D.metrics_world_size() == 1
         if dp.comm is not None:
             dp.comm.check_async_error()
         got = _flat(model)
@@ -126,7 +136,8 @@ def _worker(case, port, q):
         raise e
 
 
-@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "rccl:phased", "rccl:phased3", "torch:eager", "torch:split"])
+@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "rccl:phased", "rccl:phased3", "torch:eager", "torch:split",
+                                  "rccl:eager+metrics", "rccl:split+metrics", "rccl:phased+metrics"])
 def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

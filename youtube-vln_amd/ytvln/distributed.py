@@ -126,11 +126,13 @@ class RcclCommunicator:
             raise ValueError("RCCL unique id must be 128 bytes")
         _lib.load()
         torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        # bind to the librccl PyTorch already mapped (same HIP runtime as our streams); fall back to its file, then the loader default
-        try:
+        # bind to PyTorch's own librccl (the copy it already mapped: dlopen of the same file returns that mapping; same HIP runtime as our
+        # streams) BEFORE anything the loader's default search might find -- a second, different RCCL build in the process is what ADVICE r2
+        # warned about; only without that file fall back to "already mapped under its soname, else the loader default"
+        if os.path.exists(torch_rccl):
+            _lib.call("ytvln_rccl_load", torch_rccl.encode())
+        else:
             _lib.call("ytvln_rccl_load", None)
-        except RuntimeError:
-            _lib.call("ytvln_rccl_load", torch_rccl.encode() if os.path.exists(torch_rccl) else None)
         self.rank, self.world, self.device = rank, world, torch.device(device)
         handle = ctypes.c_void_p()
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -319,6 +321,31 @@ class GradBucketReducer:
         self._hooks = []
 
 
+_ACTIVE_DP = None        # weakref to the most recently built DataParallel: the data plane small logged-metric reductions ride on
+
+
+def metrics_world_size() -> int:
+    dp = _ACTIVE_DP() if _ACTIVE_DP is not None else None
+    if dp is not None:
+        return dp.world
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def metrics_all_reduce_(t: torch.Tensor) -> torch.Tensor:
+    """In-place SUM of a small metrics tensor over the ranks (utils/utils_init.py:176-183 reduce loss / correct / batch size for logging).
+    With the C ABI's communicator this is an RCCL call on the CURRENT stream -- no host round trip, capturable into a hipGraph; the
+    torch.distributed default group (gloo when the gradients travel over `ytvln_rccl_*`) is only used when there is no communicator
+    (the gloo path would synchronise the host in the middle of every train_step and cannot be stream-captured)."""
+    dp = _ACTIVE_DP() if _ACTIVE_DP is not None else None
+    if dp is not None and dp.comm is not None and t.is_cuda:
+        if dp.world > 1 or dp.always_exchange:
+            dp.comm.all_reduce(t if t.is_contiguous() else t.contiguous(), "sum")
+        return t
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 class DataParallel(nn.Module):
     """`wrap_distributed_model` counterpart: replicas + gradient averaging.  Use `attach(optimizer)` once.
 
@@ -343,6 +370,9 @@ class DataParallel(nn.Module):
         self._reducer: Optional[GradBucketReducer] = None
         self._opt = None
         self.require_backward_grad_sync = True
+        global _ACTIVE_DP
+        import weakref
+        _ACTIVE_DP = weakref.ref(self)
         if broadcast and (self.world > 1 or always_exchange):
             with torch.no_grad():                       # DDP broadcasts rank-0 weights at wrap time
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -481,6 +511,28 @@ class GraphedTrainStep:
             optimizer.zero_grad()
             torch.cuda.synchronize()
 
+    def layout_digest(self) -> str:
+        """What every rank must agree on before the first grouped collective: the step form, the arena size and the exact slice lists."""
+        import hashlib
+        flat = self.opt.flat_grad()
+        desc = repr((self.mode, int(flat.numel()) if flat is not None else -1, self._slices,
+                     getattr(self, "_group_slices", None), self.world))
+        return hashlib.sha256(desc.encode()).hexdigest()
+
+    def verify_layout_across_ranks(self):
+        """The phased form derives its exchange groups from what THIS rank observed while capturing; ranks that disagree would meet in
+        mismatched ncclAllReduce calls -- a hang, not an error.  Compare a digest of (mode, slices) on the control plane and raise on
+        every rank if they differ."""
+        self._verified = True
+        if not (dist.is_initialized() and self.world > 1):
+            return
+        mine = self.layout_digest()
+        every = [None] * dist.get_world_size(self.group)
+        dist.all_gather_object(every, mine, group=self.group)
+        if len(set(every)) != 1:
+            raise RuntimeError("GraphedTrainStep: ranks captured different gradient-exchange layouts "
+                               f"(mode {self.mode}; digests {sorted(set(every))}): refusing to start the exchange")
+
     # ---- phased backward: the exchange overlaps the rest of the backward pass -----------------------------------------------------
     def _capture_phased(self, fwd_bwd, optimizer, flat, cap):
         """The backward pass is cut at layer boundaries of the encoder (BertEncoder.cut_after) and captured as one graph per phase:
@@ -588,7 +640,20 @@ class GraphedTrainStep:
         self._comm_stream = torch.cuda.Stream()
         self._events = [torch.cuda.Event() for _ in graphs]
 
+    def exposed_exchange_ms(self) -> Optional[float]:
+        """With `self.profile = True`: milliseconds of the LAST step during which the compute stream had nothing left to do but wait for
+        the gradient exchange (phased: from the end of the last backward graph to the end of the last RCCL group; split: the whole
+        exchange).  Synchronises the device."""
+        ev = getattr(self, "_prof_events", None)
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return max(0.0, ev[0].elapsed_time(ev[1]))
+
     def step(self, scheduler=None) -> torch.Tensor:
+        prof = getattr(self, "profile", False)
+        if not getattr(self, "_verified", False):
+            self.verify_layout_across_ranks()
         if self.mode == "phased":
             cur = torch.cuda.current_stream()
             flat = self.opt.flat_grad()
@@ -603,6 +668,11 @@ class GraphedTrainStep:
                     self._comm_stream.wait_event(self._events[k])
                     self.comm.all_reduce_slices(flat, self._group_slices[k], stream=self._comm_stream)
             if self.exchange and self.comm is not None:
+                if prof:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    e1.record(self._comm_stream)
+                    self._prof_events = (e0, e1)
                 cur.wait_stream(self._comm_stream)
             self.opt.prepare_replay()
             self.graph_b.replay()
@@ -616,11 +686,18 @@ class GraphedTrainStep:
             self.graph_a.replay()
             if self.exchange:
                 flat = self.opt.flat_grad()
+                if prof:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 if self.comm is not None:
                     self.comm.all_reduce_slices(flat, self._slices)
                 else:
                     for lo, hi in self._slices:
                         dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                if prof:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._prof_events = (e0, e1)
             self.opt.prepare_replay()
             self.graph_b.replay()
         if scheduler is not None:

@@ -102,14 +102,29 @@ class DropoutState:
 
     @classmethod
     def get_state(cls) -> dict:
-        """{device string: (seed, counter)} -- one device->host read per device (checkpoint time only)."""
-        return {str(d): tuple(int(v) for v in t.tolist()) for d, t in cls._global.items()}
+        """{device string: (seed, counter)} of THIS process's current device -- one device->host read (checkpoint time only)."""
+        if not torch.cuda.is_available():
+            return {}
+        cur = torch.device("cuda", torch.cuda.current_device())
+        t = cls._global.get(cur)
+        if t is None:
+            return {}
+        return {str(cur): tuple(int(v) for v in t.tolist())}
 
     @classmethod
     def set_state(cls, state: dict) -> None:
-        for d, (seed, counter) in state.items():
-            dev = torch.device(d)
-            cls._global[dev] = torch.tensor([int(seed), int(counter)], dtype=torch.int64, device=dev)
+        """Restore onto the caller's CURRENT device, whatever device string the checkpoint carries (one process per GPU: a checkpoint
+        written by rank 0 on cuda:0 is resumed by rank k on cuda:k and must not make it touch cuda:0 -- ADVICE r2).  A rank whose device
+        index differs from the saved one continues the saved counter on a seed shifted by the index difference, so the ranks' mask
+        streams stay distinct the way `set_seed(seed + local_rank)` made them (utils/misc.py:37-45)."""
+        if not state or not torch.cuda.is_available():
+            return
+        cur = torch.device("cuda", torch.cuda.current_device())
+        key = str(cur) if str(cur) in state else sorted(state)[0]
+        seed, counter = state[key]
+        saved = torch.device(key)
+        shift = (cur.index or 0) - (saved.index or 0) if saved.type == "cuda" else 0
+        cls._global[cur] = torch.tensor([(int(seed) + shift) & 0x7FFFFFFFFFFFFFFF, int(counter)], dtype=torch.int64, device=cur)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -382,9 +397,21 @@ def _rows_of_grad(dy: Tensor, M: int, N: int):
     return d2, N, 0, False
 
 
-def _accumulate_target(dres, M: int, K: int):
-    """The [M, K] row view of a residual-branch gradient the input-gradient GEMM may accumulate into (beta = 1), or None."""
+def _overlaps(a: Tensor, b: Tensor) -> bool:
+    if a is None or b is None or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return False
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()
+
+
+def _accumulate_target(dres, M: int, K: int, *live):
+    """The [M, K] row view of a residual-branch gradient the input-gradient GEMM may accumulate into (beta = 1), or None.
+    `live`: tensors this backward still reads (the output gradient): with dropout p = 0 AddLayerNormFn hands the SAME storage to the
+    sublayer-output gradient and to the residual gradient, and accumulating in place would overwrite an operand that is being read
+     -- the caller then falls back to a separate buffer + add."""
     if dres is None or dres.dtype != torch.float32 or not dres.is_cuda or dres.numel() != M * K or not dres.is_contiguous():
+        return None
+    if any(_overlaps(dres, t) for t in live):
         return None
     return dres.view(M, K)
 
@@ -454,7 +481,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _bf16_eligible(M, K, N) and _bf16_eligible(N, K, M):
             st_p, st_t, db_done = _stage_bf16_dual(dy, ldy, M, N, colsum_out=db if want_db else None)   # dY read once for all its roles
         if ctx.needs_input_grad[0]:
-            acc = _accumulate_target(dres, M, K)
+            acc = _accumulate_target(dres, M, K, dy)
             if acc is not None:          # dx = d(residual) + dY W, written over the residual branch's gradient
                 _gemm(dy, ldy, 0, weight, weight.stride(0), 0, acc, K, M, K, N, beta=1.0, flags=flags, A_staged=st_p)
                 dx = acc.view(ctx.in_shape)
@@ -544,7 +571,7 @@ class FFNFn(torch.autograd.Function):
         sz_p, sz_t, db1_done = _stage_bf16_dual(dz, I, M, I, colsum_out=db1) if dual else (None, None, False)
         dx = None
         if ctx.needs_input_grad[0]:
-            acc = _accumulate_target(dres, M, K)
+            acc = _accumulate_target(dres, M, K, dy)      # (dy is consumed by now, but it may be retained / hooked upstream)
             if acc is not None:          # the residual around the FFN: accumulate into its gradient (see LinearFn)
                 _gemm(dz, I, 0, w1, w1.stride(0), 0, acc, K, M, K, I, beta=1.0, A_staged=sz_p)
                 dx = acc.view(ctx.in_shape)

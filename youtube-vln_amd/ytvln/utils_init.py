@@ -136,8 +136,9 @@ def compute_metrics_independent(batch, outputs, task, args, logger, reduced_metr
     reduced_correct = correct.detach().float()
     reduced_batch_size = torch.full((), float(batch_size), device=device)
     if getattr(args, "local_rank", -1) != -1 and not getattr(args, "skip_all_reduce", False) and dist.is_initialized():
-        packed = torch.stack([reduced_loss / float(dist.get_world_size()), reduced_correct, reduced_batch_size])
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)          # one small collective instead of the reference's three
+        from . import distributed as D
+        packed = torch.stack([reduced_loss / float(D.metrics_world_size()), reduced_correct, reduced_batch_size])
+        D.metrics_all_reduce_(packed)          # one small collective instead of the reference's three; on the RCCL data plane when there is one
         reduced_loss, reduced_correct, reduced_batch_size = packed[0], packed[1], packed[2]
     reduced_metrics["loss"][task] = reduced_loss
     if task not in ("vision", "language"):
@@ -323,9 +324,10 @@ def test_epoch(epoch: int, model, tag, data_loader, writer, default_gpu, args, g
                                             torch.ones((), device=device)])
     reduced = {task: v.clone() for task, v in stats.items()}
     if getattr(args, "local_rank", -1) != -1 and not getattr(args, "skip_all_reduce", False) and dist.is_initialized():
-        world = float(dist.get_world_size())
+        from . import distributed as D
+        world = float(D.metrics_world_size())
         for task in reduced:
-            dist.all_reduce(reduced[task], op=dist.ReduceOp.SUM)
+            D.metrics_all_reduce_(reduced[task])
             reduced[task][1] /= world
     for task in reduced:
         reduced[task][1] /= reduced[task][3]
@@ -357,7 +359,8 @@ def val_epoch(epoch: int, model, tag, data_loader, writer, default_gpu, args, gl
             stats += torch.stack([torch.full((), float(get_batch_size(batch)), device=device), loss.float(), correct])
             steps += 1
     if getattr(args, "local_rank", -1) != -1 and dist.is_initialized():
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        from . import distributed as D
+        D.metrics_all_reduce_(stats)
     success_rate = stats[2] / stats[0]
     if default_gpu and writer is not None:
         writer.add_scalar(f"loss/{task}_{tag}", float(stats[1] / max(steps, 1)), global_step=global_step)

@@ -380,7 +380,6 @@ class BertBiAttention(nn.Module):
     """Cross-stream co-attention (vilbert.py:512-618).  stream 1 = vision, stream 2 = text."""
 
     want_probs = False
-    _residuals = None        # (input_tensor1, input_tensor2) as they leave the projections' autograd nodes; consumed by BertConnectionLayer
 
     def __init__(self, config):
         super().__init__()
@@ -401,6 +400,14 @@ class BertBiAttention(nn.Module):
 
     def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
                 use_co_attention_mask=False):
+        """The reference's 3-tuple (vilbert.py:618)."""
+        return self.forward_res(input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask, use_co_attention_mask)[:3]
+
+    def forward_res(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
+                    use_co_attention_mask=False):
+        """forward() plus the two stream inputs as they leave the projections' autograd nodes (the residual values BertBiOutput adds):
+        returned, not parked on the module -- no graph stays pinned between calls and a direct forward() cannot leave a stale pair behind
+        (ADVICE r2).  BertConnectionLayer calls this form."""
         if use_co_attention_mask:
             raise NotImplementedError("use_co_attention_mask=True is dead code in the reference (vilbert.py:736) and unsupported here")
         n, r, _ = input_tensor1.shape
@@ -414,7 +421,6 @@ class BertBiAttention(nn.Module):
         q2, res2 = ops.linear_res(input_tensor2, self.query2.weight, self.query2.bias)
         kv2, res2 = ops.linear_res(res2, ops.pack_rows(self.key2.weight, self.value2.weight), ops.pack_rows(self.key2.bias, self.value2.bias))
         q1, kv1, q2, kv2 = q1.view(n * r, hb), kv1.view(n * r, 2 * hb), q2.view(n * t, hb), kv2.view(n * t, 2 * hb)
-        self._residuals = (res1, res2)          # picked up by BertConnectionLayer for BertBiOutput
         p1, p2 = _p(self, self.dropout1.p), _p(self, self.dropout2.p)
         st = _drop_state(self, q1) if (p1 > 0 or p2 > 0) else None
         s1, s2 = (st.next_site(), st.next_site()) if st else (0, 0)
@@ -429,7 +435,7 @@ class BertBiAttention(nn.Module):
                 pr2 = ops.attn_probs(q1, 0, hb, kv2, 0, 2 * hb, m2, lse2, n, self.num_attention_heads, r, t,
                                      self.attention_head_size, sc)
                 probs = (pr1, pr2)
-        return ctx1.view(n, t, hb), ctx2.view(n, r, hb), probs
+        return ctx1.view(n, t, hb), ctx2.view(n, r, hb), probs, res1, res2
 
 
 class BertBiOutput(nn.Module):
@@ -466,11 +472,9 @@ class BertConnectionLayer(nn.Module):
 
     def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
                 use_co_attention_mask=False):
-        bi_output1, bi_output2, co_attention_probs = self.biattention(
+        bi_output1, bi_output2, co_attention_probs, res1, res2 = self.biattention.forward_res(
             input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask, use_co_attention_mask)
         # bi_output2 (image queries over text) feeds the vision stream, bi_output1 the text stream (vilbert.py:671)
-        res1, res2 = self.biattention._residuals
-        self.biattention._residuals = None
         attention_output1, attention_output2 = self.biOutput(bi_output2, res1, bi_output1, res2)
         layer_output1 = _ffn_block(self.v_intermediate, self.v_output, attention_output1)
         layer_output2 = _ffn_block(self.t_intermediate, self.t_output, attention_output2)
