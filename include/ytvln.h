@@ -66,6 +66,14 @@ int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, 
 /* the same for a launch carrying YTVLN_GEMM_SPLIT_BF16X3 (its planner has its own per-tile costs; 256x256 tiles also for transA = 1 and
  * with split-K) */
 int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits);
+/* Measurement aid: with the probe enabled every following ytvln_gemm_f32 launch that takes the LDS-DMA main
+ * loop records per-workgroup clocks (s_memrealtime / s_memtime around its main loop), SYNCHRONISES the device and leaves a summary for
+ * ytvln_gemm_clock_result: out8 = {kernel us, mean main-loop us, mean main-loop shader cycles, matrix-pipe cycles the loop needs at
+ * 64 FLOP/clk/SIMD, shader clock under load in GHz (cycles / us), workgroups, mean prologue us, mean epilogue us}.  It exists because the
+ * chip's clock under fp32 matrix load depends on the operand DATA (random operands ~2.0-2.25 GHz, constant operands 2.3-2.4 GHz), so a
+ * fraction of the nominal 2.4 GHz peak mixes two things a kernel author controls only one of.  Not for production paths. */
+int ytvln_gemm_clock_probe(int enable);
+int ytvln_gemm_clock_result(double* out8);
 int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                    float beta, float* workspace, int64_t workspace_elems, int flags, void* stream);

@@ -39,8 +39,9 @@ from ytvln._lib import EPI_GELU, EPI_MUL_DGELU
 
 def run(M, N, K, ta, tb, iters=20):
     nset = max(1, COLD)
-    As = [torch.randn((K, M) if ta else (M, K), device=dev) for _ in range(nset)]
-    B = torch.randn((N, K) if tb else (K, N), device=dev)
+    fill = {"randn": torch.randn, "zeros": torch.zeros, "ones": torch.ones}[os.environ.get("DATA", "randn")]      # operand data: the chip's clock under load depends on it
+    As = [fill((K, M) if ta else (M, K), device=dev) for _ in range(nset)]
+    B = fill((N, K) if tb else (K, N), device=dev)
     Cs = [torch.randn(M, N, device=dev) for _ in range(nset)]
     aux = [torch.randn(M, N, device=dev) for _ in range(nset)] if MODE in ("gelu", "dgelu") else [None] * nset
     bias = torch.randn(N, device=dev) if MODE in ("bias", "gelu") else None

@@ -1273,8 +1273,11 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
         // opt-in (YTVLN_GEMM_SW=1): the one-wave-per-SIMD software-pipelined kernels (gemm_sw_kernel) for the 128x128 / 256x128 / 256x256 tiles
+        //   1: every such launch; 2: only launches whose epilogue READS a second matrix (beta != 0, x GELU' / x ReLU'): there the LDS-staged
+        //      epilogue (16-byte row loads, 8 in flight per lane) beats the direct one (round-3 A/B, tools/r3_gpu12.sh)
         static const int sw = getenv("YTVLN_GEMM_SW") ? atoi(getenv("YTVLN_GEMM_SW")) : 0;
-        if (sw && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
+        const bool loads = g.splits == 1 && (g.beta != 0.f || g.epilogue == YTVLN_EPI_MUL_DGELU || g.epilogue == YTVLN_EPI_MUL_DRELU);
+        if (sw && (sw == 1 || loads) && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
         if constexpr (BM == 256 && BN == 256) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
@@ -1449,6 +1452,20 @@ static void launch_bf16(GemmArgs& g, hipStream_t s, bool big_split = false) {
 
 using namespace ytvln;
 
+static int g_clock_probe = 0;
+static double g_clock_result[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+extern "C" int ytvln_gemm_clock_probe(int enable) {
+    g_clock_probe = enable != 0;
+    return 0;
+}
+
+extern "C" int ytvln_gemm_clock_result(double* out8) {
+    YT_REQUIRE(out8 != nullptr, "gemm_clock_result: NULL output");
+    for (int i = 0; i < 8; ++i) out8[i] = g_clock_result[i];
+    return 0;
+}
+
 extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
     YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan: bad argument");
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
@@ -1504,9 +1521,10 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     g.asum = nullptr; g.asum_ws = nullptr;
     static const int probe = getenv("YTVLN_GEMM_PROBE") ? atoi(getenv("YTVLN_GEMM_PROBE")) : 0;
     g.probe = probe;
-    static const int dbg_on = getenv("YTVLN_GEMM_DBG") ? atoi(getenv("YTVLN_GEMM_DBG")) : 0;
+    static const int dbg_env = getenv("YTVLN_GEMM_DBG") ? atoi(getenv("YTVLN_GEMM_DBG")) : 0;     // n: print the clocks of call number n
     static unsigned long long* dbg_buf = nullptr;
     static int dbg_calls = 0;
+    const int dbg_on = dbg_env || g_clock_probe;
     g.dbg = nullptr;
     if (dbg_on) {
         if (!dbg_buf) hipMalloc(&dbg_buf, 8192 * 8 * sizeof(unsigned long long));
@@ -1583,7 +1601,8 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
         else launch_tile<64, 64>(g, transA, transB, s);
     }
     YT_LAUNCH_CHECK("gemm_f32");
-    if (dbg_on && ++dbg_calls == dbg_on) {          // debugging aid: dump the clocks of call number YTVLN_GEMM_DBG
+    ++dbg_calls;
+    if ((dbg_env && dbg_calls == dbg_env) || g_clock_probe) {          // clock probe / debugging aid (synchronises the device)
         hipDeviceSynchronize();
         const int nb = g.ntiles * g.splits;
         std::vector<unsigned long long> h((size_t)nb * 8);
@@ -1601,8 +1620,11 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
         (void)tile_cyc;
         const int bm = (int)cdiv(M, g.tiles_m), bn = (int)cdiv(N, g.tiles_n);       // (approximate tile extents)
         const double ideal = (double)h[6] * 32.0 * ((bm + 31) / 32 * 32) * ((bn + 31) / 32 * 32) * 2.0 / 256.0;   // matrix-pipe cycles of one workgroup's loop
-        fprintf(stderr, "gemmdbg %d x %d x %d tA%d tB%d: %d workgroups, kernel %.1f us, prologue %.1f, loop %.1f (%.0f cycles = %.3f of the matrix pipe, clock %.3f GHz), epilogue %.1f us\n",
-                M, N, K, transA, transB, nb, (t3 - t0) * 0.01, pro, loop_us, cyc, ideal / cyc, cyc / loop_us * 1e-3, epi);
+        g_clock_result[0] = (t3 - t0) * 0.01; g_clock_result[1] = loop_us; g_clock_result[2] = cyc; g_clock_result[3] = ideal;
+        g_clock_result[4] = cyc / loop_us * 1e-3; g_clock_result[5] = (double)nb; g_clock_result[6] = pro; g_clock_result[7] = epi;
+        if (dbg_env)
+            fprintf(stderr, "gemmdbg %d x %d x %d tA%d tB%d: %d workgroups, kernel %.1f us, prologue %.1f, loop %.1f (%.0f cycles = %.3f of the matrix pipe, clock %.3f GHz), epilogue %.1f us\n",
+                    M, N, K, transA, transB, nb, (t3 - t0) * 0.01, pro, loop_us, cyc, ideal / cyc, cyc / loop_us * 1e-3, epi);
     }
     return 0;
 }

@@ -47,6 +47,8 @@ SIGNATURES = {
     "ytvln_attn_fwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
     "ytvln_attn_bwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
     "ytvln_gemm_plan": [I32, I32, I32, I32, I32, P, P, P],
+    "ytvln_gemm_clock_probe": [I32],
+    "ytvln_gemm_clock_result": [P],
     "ytvln_gemm_plan_x3": [I32, I32, I32, I32, I32, P, P, P],
     "ytvln_cast_bf16_dual": [P, I64, I32, I32, P, I64, P, I64, P],
     "ytvln_cast_bf16_dual_colsum": [P, I64, I32, I32, P, I64, P, I64, P, P],
