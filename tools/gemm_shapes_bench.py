@@ -37,7 +37,7 @@ COLD = int(os.environ.get("COLD", "0"))        # > 0: rotate over that many oper
 from ytvln._lib import EPI_GELU, EPI_MUL_DGELU
 
 
-def run(M, N, K, ta, tb, iters=20):
+def run(M, N, K, ta, tb, iters=int(os.environ.get("ITERS", "20"))):
     nset = max(1, COLD)
     fill = {"randn": torch.randn, "zeros": torch.zeros, "ones": torch.ones}[os.environ.get("DATA", "randn")]      # operand data: the chip's clock under load depends on it
     As = [fill((K, M) if ta else (M, K), device=dev) for _ in range(nset)]
