@@ -787,6 +787,27 @@ def main():
             out.setdefault("variants", {})["bf16"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             yt_ops.set_matmul_precision("fp32")
+        if a.workload == "cfg2_full_pretrain_bs8":
+            # BASELINE configs[4] at ITS size (bs 32 items = 224 pairs per GPU, 16 frames x 36 = 576 regions, bf16 MFMA operands) in its own
+            # process after everything above -- so that the driver's default run sees that number too, with its own roofline against the
+            # dense bf16 peak.  NOT the headline.
+            try:
+                import subprocess
+                torch.cuda.empty_cache()
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg5_long_traj_bs32", "--precision", "bf16", "--no-variants",
+                       "--no-cpu-baseline", "--steps", "4", "--warmup", "2"]
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                c5 = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                GF5 = 384.4          # algorithmic GFLOP per training pair at T = 80, R = 576
+                out.setdefault("variants", {})["cfg5_bf16"] = {
+                    "value": c5["value"], "unit": "pairs/s", "ms_per_step": c5["ms_per_step"], "workload": c5["config"]["workload"],
+                    "pairs_per_gpu": c5["config"]["pairs_per_gpu"], "regions": c5["config"]["regions"], "dtype": c5["dtype"],
+                    "model_tflops": round(c5["value"] * GF5 / 1000.0, 1), "model_frac_of_bf16_peak": round(c5["value"] * GF5 / 1000.0 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "roofline": {k: c5["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us") if k in c5.get("roofline", {})},
+                    "families": c5.get("roofline", {}).get("families"),
+                    "note": "BASELINE configs[4] per-GPU workload in a separate process (python bench.py --workload cfg5_long_traj_bs32 --precision bf16); not the headline"}
+            except Exception as e:
+                out.setdefault("variants", {})["cfg5_bf16"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not dp_wrap and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.workload)
     if rank == 0:

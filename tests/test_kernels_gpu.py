@@ -631,6 +631,58 @@ def test_gemm_fp32_split_bf16x3_dynamic_range(dev, lib):
     assert rel < 2e-6, rel
 
 
+def test_gemm_fp32_split_bf16x3_adversarial_error_bound(dev, lib):
+    """adversarial operands for the three-term form next to the native instruction, both against fp64, error measured in
+    units of sum_k |a||b| (the forward error scale of a dot product; an fp32 accumulation of K terms is allowed ~K^0.5 .. K ulps of it):
+      * catastrophic cancellation: every row of A is paired with columns built so that the exact dot product is ~1e-7 of sum |a||b|;
+      * mixed signs over a long contraction (K = 8192) with magnitudes spread over 2^-20 .. 2^20 inside one dot product;
+      * denormal-adjacent: operands at 2^-126 .. 2^-100 whose PRODUCTS are far below the fp32 range except against a large partner
+        (the split terms mid / lo of such values are themselves subnormal or zero: the split must stay exact);
+      * values with all 24 significand bits set (worst case for the hi / mid / lo split).
+    The three-term result must stay within 4x the native kernel's own error bound on every case and must not be worse than 3x the native
+    kernel's measured error (plus a small floor), i.e. it is an fp32-level arithmetic on these inputs too, not a reduced-precision mode."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(99)
+
+    def run(A, B, mode):
+        M, K = A.shape
+        N = B.shape[0]
+        C = torch.empty(M, N, device=dev)
+        ops.set_matmul_precision(mode)
+        try:
+            ops._gemm(A.to(dev), K, 0, B.to(dev), K, 1, C, N, M, N, K)
+        finally:
+            ops.set_matmul_precision("fp32")
+        return C.double().cpu()
+
+    cases = {}
+    M, N, K = 256, 256, 2048
+    # cancellation: B's second half of the contraction is the negated first half plus a 1e-7 relative perturbation
+    a = torch.randn(M, K // 2, generator=g)
+    b = torch.randn(N, K // 2, generator=g)
+    cases["cancellation"] = (torch.cat([a, a], 1), torch.cat([b, -b * (1 + 1e-7 * torch.randn(N, K // 2, generator=g))], 1))
+    K2 = 8192
+    mag = 2.0 ** torch.randint(-20, 21, (1, K2), generator=g).float()
+    cases["mixed_sign_long_k"] = (torch.randn(M, K2, generator=g) * mag, torch.randn(N, K2, generator=g) / mag * torch.sign(torch.randn(N, K2, generator=g)))
+    tiny = 2.0 ** torch.randint(-126, -99, (M, K), generator=g).float() * torch.sign(torch.randn(M, K, generator=g))
+    huge = 2.0 ** torch.randint(90, 120, (N, K), generator=g).float() * (1 + torch.rand(N, K, generator=g))
+    cases["denormal_adjacent"] = (tiny, huge)
+    full = torch.full((M, K), float.fromhex("0x1.fffffep+0")) * torch.sign(torch.randn(M, K, generator=g))
+    cases["all_significand_bits"] = (full, torch.full((N, K), float.fromhex("0x1.fffffep-1")) * (1 + 2.0 ** -23 * torch.randint(0, 2, (N, K), generator=g).float()))
+    for name, (A, B) in cases.items():
+        A, B = A.float().contiguous(), B.float().contiguous()
+        assert torch.isfinite(A).all() and torch.isfinite(B).all()
+        ref = A.double() @ B.double().t()
+        scale = A.double().abs() @ B.double().abs().t()
+        e_nat = float(((run(A, B, "fp32") - ref).abs() / scale).max())
+        e_x3 = float(((run(A, B, "fp32x3") - ref).abs() / scale).max())
+        kk = A.shape[1]
+        bound = 6e-8 * (kk ** 0.5) * 4.0          # ~4 x (unit roundoff x sqrt(K)): the native kernel's own accumulation noise
+        assert e_nat < bound, (name, "native", e_nat, bound)
+        assert e_x3 < bound, (name, "fp32x3", e_x3, bound)
+        assert e_x3 < 3.0 * e_nat + 2e-7, (name, e_x3, e_nat)
+
+
 def test_edge_cases_and_loud_failures(dev, lib):
     """Empty problems are no-ops; illegal arguments raise with the library's message (no silent fallback of any kind)."""
     from ytvln import ops
