@@ -716,18 +716,168 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM
 //   group 3 of tile t    : matrix instructions on F[1]  ||  DMA of tile t + NS into the slot of tile t (every wave is done reading it)
 //                                                       ||  reads of (t + 1, group 0) -> F[0]
 // so NS slots keep NS - 1 tiles of DMA in flight under a full tile of matrix work each.
+// Cross-XCD exchange of stream-K partial tiles without cache-wide fences (guide, section 5.7): write-through (sc1) 16-byte stores,
+// vmcnt drain, workgroup barrier, ONE relaxed agent-scope flag store; the owner polls the flag relaxed (an acquire poll would invalidate
+// its L1 on every iteration) and reads the slab with sc1 loads.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1(float* p, v4f v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ v4f load_sc1(const float* p) {      // the caller waits (s_waitcnt vmcnt(0)) before using the value
+    v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// The main loop of the one-wave-per-SIMD kernels as a callable: k-tiles [kbeg / 32, kbeg / 32 + nk) of the block tile at (m0, n0) are
+// accumulated into `acc` (zeroed by the caller).  On return no DMA is in flight and this wave has read everything it needed from the ring;
+// the caller puts a workgroup barrier between two calls (and before it reuses the ring as epilogue staging space).
 template <int BM, int BN, bool A_KC, bool B_KC, int NS>
-__global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
-    constexpr int NW = 4, KB = 32;
+struct SwLoop {
+    static constexpr int NW = 4, KB = 32;
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
-    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;  // waves 2 (m) x 2 (n)
-    constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
-    constexpr int NPT = TA::NI + TB::NI;
-    constexpr int NMF = TM * TN * 4;                    // matrix instructions per k-group
-    constexpr int RDS = (A_KC ? TM : 4 * TM) + (B_KC ? TN : 4 * TN);   // LDS read instructions per k-group
+    static constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;  // waves 2 (m) x 2 (n)
+    static constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
+    static constexpr int NPT = TA::NI + TB::NI;
+    static constexpr int NMF = TM * TN * 4;                    // matrix instructions per k-group
     static_assert(NS >= 2 && NS <= 4 && NS * STAGE * 4 <= 160 * 1024, "ring does not fit the LDS");
-    __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];
+
+    __device__ static __forceinline__ void run(const GemmArgs& g, float* __restrict__ smem, int m0, int n0, int kbeg, int nk, bool tail_here,
+                                               f32x16 (&acc)[TM][TN], float (&asum)[TM], bool do_asum, int wave, int lane,
+                                               unsigned long long* dbg_t1, unsigned long long* dbg_c1) {
+        const int l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+        const float* pa[TA::NI];
+        const float* pb[TB::NI];
+    #pragma unroll
+        for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg, wave, lane, i, 0x7fffffff);
+    #pragma unroll
+        for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg, wave, lane, i, 0x7fffffff);
+        const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
+
+        int st_in = 0;
+        auto issue = [&](int kt) {
+            float* As = smem + st_in * STAGE;
+            float* Bs = As + SA;
+            st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
+            if (tail_here && kbeg + (kt + 1) * KB > g.K) {
+    #pragma unroll
+                for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * KB, wave, lane, i, g.K - 1);
+    #pragma unroll
+                for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * KB, wave, lane, i, g.K - 1);
+            }
+    #pragma unroll
+            for (int i = 0; i < TA::NI; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
+                pa[i] += sa;
+            }
+    #pragma unroll
+            for (int i = 0; i < TB::NI; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
+                pb[i] += sb;
+            }
+        };
+        auto retire = [&](int left) {         // wait for this wave's oldest outstanding tile; `left` younger tiles stay in flight
+            if (NS >= 4 && left >= 2) wait_vmcnt<2 * NPT>();
+            else if (NS >= 3 && left >= 1) wait_vmcnt<NPT>();
+            else wait_vmcnt<0>();
+        };
+
+        float4 fa[2][TM], fb[2][TN];
+        constexpr int NFR = TM + TN;                        // fragments per k-group
+        static_assert(NFR + NPT <= NMF, "more loads than matrix instructions in a k-group");
+        // (every register-array index below is a compile-time constant: a run-time index makes hipcc move the fragment arrays to scratch LDS)
+        // fragment R of k-group sg: the A fragments first, then the B fragments (one ds_read_b128, or four ds_read_b32 of a k-major image)
+        auto rd1 = [&](auto BUF, auto R, const float* __restrict__ As, const float* __restrict__ Bs, int sg) __attribute__((always_inline)) {
+            constexpr int buf = decltype(BUF)::value, r = decltype(R)::value;
+            if constexpr (r < TM) fa[buf][r] = TA::frag(As, wm0, r, l31, half, sg);
+            else fb[buf][r - TM] = TB::frag(Bs, wn0, r - TM, l31, half, sg);
+        };
+        auto mma1 = [&](auto BUF, auto K) __attribute__((always_inline)) {      // matrix instruction K of a group: k-major, accumulators alternate
+            constexpr int buf = decltype(BUF)::value, k = decltype(K)::value;
+            constexpr int c = k / (TM * TN), i = (k / TN) % TM, j = k % TN;
+            const float av = c == 0 ? fa[buf][i].x : c == 1 ? fa[buf][i].y : c == 2 ? fa[buf][i].z : fa[buf][i].w;
+            const float bv = c == 0 ? fb[buf][j].x : c == 1 ? fb[buf][j].y : c == 2 ? fb[buf][j].z : fb[buf][j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+        };
+        // One k-group: matrix instruction k on F[CUR], then (pinned behind it) fragment k of the NEXT group into F[CUR ^ 1], then -- group 3 of a
+        // steady tile -- DMA piece k - NFR of tile kt + NS.  sched_barrier(0) after every step: the order IS the schedule.
+        auto group = [&](auto CUR, auto DMA_TAG, const float* __restrict__ As, const float* __restrict__ Bs, int sg_next, bool reads, float* Ad) __attribute__((always_inline)) {
+            constexpr int cur = decltype(CUR)::value;
+            constexpr bool DMA = decltype(DMA_TAG)::value;
+            if constexpr (!A_KC) {
+                if (do_asum) {
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) asum[i] += (fa[cur][i].x + fa[cur][i].y) + (fa[cur][i].z + fa[cur][i].w);
+                }
+            }
+            static_for<NMF>([&](auto K) __attribute__((always_inline)) {
+                constexpr int k = decltype(K)::value;
+                mma1(CUR, K);
+                if constexpr (k < NFR) {
+                    if (reads && !(g.probe & 2)) rd1(std::integral_constant<int, cur ^ 1>{}, K, As, Bs, sg_next);
+                }
+                if constexpr (DMA && k >= NFR && k - NFR < TA::NI) {
+                    constexpr int d = k - NFR;
+                    if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[d], (lds_ptr_t)(Ad + (wave * TA::NI + d) * 256), 16, 0, 0);
+                    pa[d] += sa;
+                } else if constexpr (DMA && k >= NFR + TA::NI && k - NFR < NPT) {
+                    constexpr int e = k - NFR - TA::NI;
+                    if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[e], (lds_ptr_t)(Ad + SA + (wave * TB::NI + e) * 256), 16, 0, 0);
+                    pb[e] += sb;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+
+        const int npro = min(nk, NS);
+        for (int t = 0; t < npro; ++t) issue(t);
+        retire(npro - 1);
+        __builtin_amdgcn_s_barrier();
+        if (g.dbg && dbg_t1) { *dbg_t1 = __builtin_amdgcn_s_memrealtime(); *dbg_c1 = __builtin_amdgcn_s_memtime(); }
+        static_for<NFR>([&](auto R) __attribute__((always_inline)) { rd1(I0{}, R, smem, smem + SA, 0); });
+
+        int st_out = 0;
+        // STEADY tiles (every tile but the last NS + 1) have no K tail, always issue tile kt + NS and always read tile kt + 1: their body is
+        // ONE basic block, so the DMA issues and the next tile's first reads sit between the matrix instructions of k-group 3.
+        auto tile = [&](auto steady_tag, int kt) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
+            const float* As = smem + st_out * STAGE;
+            const float* Bs = As + SA;
+            st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
+            const float* An = smem + st_out * STAGE;      // next tile's slot
+            group(I0{}, std::false_type{}, As, Bs, 1, true, nullptr);
+            group(I1{}, std::false_type{}, As, Bs, 2, true, nullptr);
+            group(I0{}, std::false_type{}, As, Bs, 3, true, nullptr);
+            if constexpr (STEADY) wait_vmcnt<(NS - 2) * NPT>();       // my pieces of tile kt + 1; tiles kt + 2 .. kt + NS - 1 stay in flight
+            else if (kt + 1 < nk) retire(min(NS - 2, nk - 2 - kt));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of (kt, group 3): the slot may be overwritten behind the barrier
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STEADY) {
+                float* Ad = smem + st_in * STAGE;
+                st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
+                group(I1{}, std::true_type{}, An, An + SA, 0, true, Ad);
+            } else {
+                if (kt + NS < nk) issue(kt + NS);
+                group(I1{}, std::false_type{}, An, An + SA, 0, kt + 1 < nk, nullptr);
+            }
+        };
+        int kt = 0;
+        for (; kt < nk - NS - 1; ++kt) tile(std::true_type{}, kt);
+        for (; kt < nk; ++kt) tile(std::false_type{}, kt);
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NS>
+__global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
+    using L = SwLoop<BM, BN, A_KC, B_KC, NS>;
+    constexpr int TM = L::TM, TN = L::TN, KB = L::KB;
+    __shared__ __attribute__((aligned(16))) float smem[NS * L::STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -738,14 +888,6 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
     const int kend = min(g.Kloop, kbeg + g.kchunk);
     const int nk = (kend - kbeg) / KB;
     const bool tail_here = g.ktail && kend == g.Kloop;
-
-    const float* pa[TA::NI];
-    const float* pb[TB::NI];
-#pragma unroll
-    for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg, wave, lane, i, 0x7fffffff);
-#pragma unroll
-    for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg, wave, lane, i, 0x7fffffff);
-    const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -760,122 +902,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
-    int st_in = 0;
-    auto issue = [&](int kt) {
-        float* As = smem + st_in * STAGE;
-        float* Bs = As + SA;
-        st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
-        if (tail_here && kbeg + (kt + 1) * KB > g.K) {
-#pragma unroll
-            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * KB, wave, lane, i, g.K - 1);
-#pragma unroll
-            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * KB, wave, lane, i, g.K - 1);
-        }
-#pragma unroll
-        for (int i = 0; i < TA::NI; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
-            pa[i] += sa;
-        }
-#pragma unroll
-        for (int i = 0; i < TB::NI; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
-            pb[i] += sb;
-        }
-    };
-    auto retire = [&](int left) {         // wait for this wave's oldest outstanding tile; `left` younger tiles stay in flight
-        if (NS >= 4 && left >= 2) wait_vmcnt<2 * NPT>();
-        else if (NS >= 3 && left >= 1) wait_vmcnt<NPT>();
-        else wait_vmcnt<0>();
-    };
-
-    float4 fa[2][TM], fb[2][TN];
-    constexpr int NFR = TM + TN;                        // fragments per k-group
-    static_assert(NFR + NPT <= NMF, "more loads than matrix instructions in a k-group");
-    // (every register-array index below is a compile-time constant: a run-time index makes hipcc move the fragment arrays to scratch LDS)
-    // fragment R of k-group sg: the A fragments first, then the B fragments (one ds_read_b128, or four ds_read_b32 of a k-major image)
-    auto rd1 = [&](auto BUF, auto R, const float* __restrict__ As, const float* __restrict__ Bs, int sg) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::value, r = decltype(R)::value;
-        if constexpr (r < TM) fa[buf][r] = TA::frag(As, wm0, r, l31, half, sg);
-        else fb[buf][r - TM] = TB::frag(Bs, wn0, r - TM, l31, half, sg);
-    };
-    auto mma1 = [&](auto BUF, auto K) __attribute__((always_inline)) {      // matrix instruction K of a group: k-major, accumulators alternate
-        constexpr int buf = decltype(BUF)::value, k = decltype(K)::value;
-        constexpr int c = k / (TM * TN), i = (k / TN) % TM, j = k % TN;
-        const float av = c == 0 ? fa[buf][i].x : c == 1 ? fa[buf][i].y : c == 2 ? fa[buf][i].z : fa[buf][i].w;
-        const float bv = c == 0 ? fb[buf][j].x : c == 1 ? fb[buf][j].y : c == 2 ? fb[buf][j].z : fb[buf][j].w;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-    };
-    // One k-group: matrix instruction k on F[CUR], then (pinned behind it) fragment k of the NEXT group into F[CUR ^ 1], then -- group 3 of a
-    // steady tile -- DMA piece k - NFR of tile kt + NS.  sched_barrier(0) after every step: the order IS the schedule.
-    auto group = [&](auto CUR, auto DMA_TAG, const float* __restrict__ As, const float* __restrict__ Bs, int sg_next, bool reads, float* Ad) __attribute__((always_inline)) {
-        constexpr int cur = decltype(CUR)::value;
-        constexpr bool DMA = decltype(DMA_TAG)::value;
-        if constexpr (!A_KC) {
-            if (do_asum) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) asum[i] += (fa[cur][i].x + fa[cur][i].y) + (fa[cur][i].z + fa[cur][i].w);
-            }
-        }
-        static_for<NMF>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            mma1(CUR, K);
-            if constexpr (k < NFR) {
-                if (reads && !(g.probe & 2)) rd1(std::integral_constant<int, cur ^ 1>{}, K, As, Bs, sg_next);
-            }
-            if constexpr (DMA && k >= NFR && k - NFR < TA::NI) {
-                constexpr int d = k - NFR;
-                if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[d], (lds_ptr_t)(Ad + (wave * TA::NI + d) * 256), 16, 0, 0);
-                pa[d] += sa;
-            } else if constexpr (DMA && k >= NFR + TA::NI && k - NFR < NPT) {
-                constexpr int e = k - NFR - TA::NI;
-                if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[e], (lds_ptr_t)(Ad + SA + (wave * TB::NI + e) * 256), 16, 0, 0);
-                pb[e] += sb;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-
     unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_c1 = 0;
     if (g.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
-    const int npro = min(nk, NS);
-    for (int t = 0; t < npro; ++t) issue(t);
-    retire(npro - 1);
-    __builtin_amdgcn_s_barrier();
-    if (g.dbg) { dbg_t1 = __builtin_amdgcn_s_memrealtime(); dbg_c1 = __builtin_amdgcn_s_memtime(); }
-    static_for<NFR>([&](auto R) __attribute__((always_inline)) { rd1(I0{}, R, smem, smem + SA, 0); });
-
-    int st_out = 0;
-    // STEADY tiles (every tile but the last NS + 1) have no K tail, always issue tile kt + NS and always read tile kt + 1: their body is
-    // ONE basic block, so the DMA issues and the next tile's first reads sit between the matrix instructions of k-group 3.
-    auto tile = [&](auto steady_tag, int kt) __attribute__((always_inline)) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const float* As = smem + st_out * STAGE;
-        const float* Bs = As + SA;
-        st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
-        const float* An = smem + st_out * STAGE;      // next tile's slot
-        group(I0{}, std::false_type{}, As, Bs, 1, true, nullptr);
-        group(I1{}, std::false_type{}, As, Bs, 2, true, nullptr);
-        group(I0{}, std::false_type{}, As, Bs, 3, true, nullptr);
-        if constexpr (STEADY) wait_vmcnt<(NS - 2) * NPT>();       // my pieces of tile kt + 1; tiles kt + 2 .. kt + NS - 1 stay in flight
-        else if (kt + 1 < nk) retire(min(NS - 2, nk - 2 - kt));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of (kt, group 3): the slot may be overwritten behind the barrier
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (STEADY) {
-            float* Ad = smem + st_in * STAGE;
-            st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
-            group(I1{}, std::true_type{}, An, An + SA, 0, true, Ad);
-        } else {
-            if (kt + NS < nk) issue(kt + NS);
-            group(I1{}, std::false_type{}, An, An + SA, 0, kt + 1 < nk, nullptr);
-        }
-    };
-    int kt = 0;
-    for (; kt < nk - NS - 1; ++kt) tile(std::true_type{}, kt);
-    for (; kt < nk; ++kt) tile(std::false_type{}, kt);
+    L::run(g, smem, m0, n0, kbeg, nk, tail_here, acc, asum, do_asum, wave, lane, &dbg_t1, &dbg_c1);
     if constexpr (!A_KC) {
         if (do_asum) {
 #pragma unroll
@@ -892,7 +921,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_barrier();        // every wave is done reading the ring (and no DMA is in flight): it becomes the epilogue's staging space
     unsigned long long dbg_t2 = 0, dbg_c2 = 0;
     if (g.dbg) { dbg_t2 = __builtin_amdgcn_s_memrealtime(); dbg_c2 = __builtin_amdgcn_s_memtime(); }
-    static_assert(4 * 64 * 32 * TN * 4 <= NS * STAGE * 4, "epilogue staging does not fit the ring");
+    static_assert(4 * 64 * 32 * TN * 4 <= NS * L::STAGE * 4, "epilogue staging does not fit the ring");
     epilogue_lds<TM, TN>(g, acc, smem + wave * (64 * 32 * TN), m0 + wm0, n0 + wn0, lane, tc.split);
     if (g.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -946,19 +975,6 @@ void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsign
 }
 }  // namespace ytvln
 #else       // ---- everything below belongs to the main translation unit -------------------------------------------------------------
-
-// Cross-XCD exchange of stream-K partial tiles without cache-wide fences (guide, section 5.7): write-through (sc1) 16-byte stores,
-// vmcnt drain, workgroup barrier, ONE relaxed agent-scope flag store; the owner polls the flag relaxed (an acquire poll would invalidate
-// its L1 on every iteration) and reads the slab with sc1 loads.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_sc1(float* p, v4f v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ v4f load_sc1(const float* p) {      // the caller waits (s_waitcnt vmcnt(0)) before using the value
-    v4f v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
 
 // ---- stream-K ---------------------------------------------------------------------------------------------------------------------
 // For outputs whose 128x128 tile count does not fill whole waves of the 256 CUs (the 4480-row text-stream projections: 35 x 6 = 210
@@ -1198,6 +1214,9 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
     // epilogue.  Measured on the 4480- and 7680-row text shapes it fills the idle CUs (+22 %) but pays ~30-35 us per workgroup for the
     // partial-tile round trip and the second pipeline fill, all workgroups in lock-step: 0.97x / 0.95x of the best ordinary plan.
     // Kept as an opt-in (YTVLN_GEMM_STREAMK=1: when the model predicts a win, =2: whenever legal); off by default.
+    // Round 3 rebuilt the schedule on the one-wave-per-SIMD main loop (SwLoop, 0.87-0.90 of the pipe with one workgroup per CU): 0.90-1.0x of
+    // the default plans on every text shape (profiles/round3_streamk_sw.log) -- with all CUs busy the chip clocks down, so the
+    // idle 18 % of a 210-tile round is not recoverable throughput.  That kernel was removed again.
     static const int sk_on = getenv("YTVLN_GEMM_STREAMK") ? atoi(getenv("YTVLN_GEMM_STREAMK")) : 0;
     if (sk_ok && !x3 && sk_on && force_tile < 0 && force_sp < 0 && K % BK == 0) {
         const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), nkt = K / BK;
