@@ -596,12 +596,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
 // small run-time loop over rows instead of a fully unrolled, ten-times specialised store sequence (the unrolled form of a 4 x 4 sub-tile
 // wave is ~1 MB of code per kernel and spills).  `wlds`: this wave's private LDS region, 64 x (32 TN) floats; two passes for TM = 4.
 // Same arithmetic per element as epilogue_body (bias add, then activation, then beta * old), so results are bit-identical.
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* __restrict__ wlds, int row0, int col0, int lane, int split) {
-    constexpr int W = 32 * TN, W4 = W / 4;              // floats / 16-byte groups per staged row
-    constexpr int IB = TM >= 2 ? 2 : 1;                 // 32-row blocks per pass
+// (`stage(PASS)` writes rows [PROWS * pass, PROWS * (pass + 1)) of the wave tile into wlds[row][W] -- the only part that knows the accumulator layout)
+template <int W, int PROWS, int NPASS, class Stage>
+__device__ __forceinline__ void epilogue_lds_rows(const GemmArgs& g, float* __restrict__ wlds, int row0, int col0, int lane, int split, Stage&& stage) {
+    constexpr int W4 = W / 4;                           // 16-byte groups per staged row
     constexpr int RPI = 64 / W4;                        // rows covered by one wave-wide 16-byte access
-    const int l31 = lane & 31, half = lane >> 5;
     const bool partial = g.splits > 1;
     float* const Cb = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
     const int64_t ldc = partial ? g.N : g.ldc;
@@ -618,21 +617,14 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM
 #pragma unroll
         for (int u = 0; u < 4; ++u) bv[u] = col + u < g.N ? bias[col + u] : 0.f;
     }
-    static_for<TM / IB>([&](auto PASS) __attribute__((always_inline)) {
-        constexpr int i0 = decltype(PASS)::value * IB;       // (compile-time: a run-time index would move the accumulators to scratch memory)
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    wlds[(32 * ii + (r & 3) + 8 * (r >> 2) + 4 * half) * W + 32 * j + l31] = acc[i0 + ii][j][r];
+    static_for<NPASS>([&](auto PASS) __attribute__((always_inline)) {
+        stage(PASS);                                         // (compile-time pass index: a run-time one would move the accumulators to scratch memory)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int rbase = row0 + 32 * i0;
+        const int rbase = row0 + PROWS * decltype(PASS)::value;
         auto rows = [&](auto EPI_TAG) __attribute__((always_inline)) {
             constexpr int EPI = decltype(EPI_TAG)::value;
             constexpr bool AUXLD = EPI == YTVLN_EPI_MUL_DGELU || EPI == YTVLN_EPI_MUL_DRELU;
-            constexpr int NIT = 32 * IB / RPI, CH = 8;           // CH row accesses at a time: their global loads are in flight together
+            constexpr int NIT = PROWS / RPI, CH = 8;             // CH row accesses at a time: their global loads are in flight together
             static_assert(NIT % CH == 0, "chunking");
             for (int it0 = 0; it0 < NIT; it0 += CH) {
                 float4 t[CH], o[CH], a[CH];
@@ -699,6 +691,22 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM
             case YTVLN_EPI_MUL_DRELU: rows(std::integral_constant<int, YTVLN_EPI_MUL_DRELU>{}); break;
             default: rows(std::integral_constant<int, YTVLN_EPI_NONE>{}); break;
         }
+    });
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* __restrict__ wlds, int row0, int col0, int lane, int split) {
+    constexpr int W = 32 * TN, IB = TM >= 2 ? 2 : 1;    // floats per staged row; 32-row blocks per pass
+    const int l31 = lane & 31, half = lane >> 5;
+    epilogue_lds_rows<W, 32 * IB, TM / IB>(g, wlds, row0, col0, lane, split, [&](auto PASS) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(PASS)::value * IB;
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wlds[(32 * ii + (r & 3) + 8 * (r >> 2) + 4 * half) * W + 32 * j + l31] = acc[i0 + ii][j][r];
     });
 }
 
