@@ -711,7 +711,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM
 }
 
 // ---- one wave per SIMD, software-pipelined main loop (round 3) -----------------------------------------------------------------------
-// What the round-3 probes measured (tools/lab/gen_mfma_lds_bench.py, tools/r3_gpu2-5.sh): while one wave of a SIMD
+// What the round-3 probes measured (tools/lab/gen_mfma_lds_bench.py, profiles/round3_pp_probes.log): while one wave of a SIMD
 // streams fp32 matrix instructions, the OTHER wave of that SIMD gets about one vector-memory / LDS / VALU instruction issued per matrix
 // instruction (64 cycles) -- a 35-instruction operand-load phase takes ~2100-2300 cycles beside a 2048-cycle matrix phase, which is what
 // holds gemm_dma_kernel (and the ping-pong form above) at 0.80-0.90 of the matrix peak.  The same instructions placed INSIDE the
