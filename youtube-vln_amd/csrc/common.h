@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <math.h>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/ytvln.h"
 
@@ -28,6 +30,13 @@ int fail(int code, const char* fmt, ...);
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).  Register arrays indexed through it
+// stay in registers (a run-time index, even of a fully unrolled loop variable captured by a lambda, can demote them to scratch).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // ---- Philox4x32-10 counter RNG (dropout masks reproducible between forward and backward) ----------------------
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -46,11 +55,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 // Key of one dropout site: rng[0] = seed, rng[1] = forward counter (device memory), site = host call-site id.
 struct DropKey { uint32_t k0, k1, s0, s1; };
-__device__ __forceinline__ DropKey make_drop_key(const int64_t* rng, int64_t site) {
-    const uint64_t seed = (uint64_t)rng[0], ctr = (uint64_t)rng[1];
+__device__ __forceinline__ DropKey drop_key_of(uint64_t seed, uint64_t ctr, int64_t site) {      // (seed, ctr) already loaded by the caller
     const uint64_t mix = seed ^ (ctr * 0x9E3779B97F4A7C15ull);
     return {(uint32_t)mix, (uint32_t)(mix >> 32), (uint32_t)site, (uint32_t)((uint64_t)site >> 32) ^ (uint32_t)(ctr >> 17)};
 }
+__device__ __forceinline__ DropKey make_drop_key(const int64_t* rng, int64_t site) { return drop_key_of((uint64_t)rng[0], (uint64_t)rng[1], site); }
 // Four keep-flags/uniforms for elements [4*q, 4*q+3] of the site's flat element space.
 __device__ __forceinline__ u32x4 drop_bits(const DropKey& k, uint64_t q) {
     return philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), k.s0, k.s1, k.k0, k.k1);

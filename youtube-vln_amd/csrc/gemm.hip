@@ -358,11 +358,6 @@ struct DmaTile {
     }
 };
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -1163,6 +1158,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //  * per block: a fixed cost (prologue DMA round trip + epilogue) plus k-tiles at the CU-exclusive rate of the tile shape
 //    (128x128 / 8 waves: 2.14 us per 32-deep k-tile; 128x64 and 64x64 / 4 waves: 1.14 and 0.55 us);
 //  * split-K (plain epilogues only, 128x128 tiles) adds the workspace round trip and the reduce launch.
+//    (Round 3, measured and removed: the reduction INSIDE the GEMM -- partials dumped in fragment order with sc1 stores, an arrival counter
+//     per tile, the last workgroup to arrive adds them in split order.  Bit-identical to the separate pass, but one workgroup per output
+//     tile moves splits x tile bytes at a latency-bound ~50 GB/s while the separate pass uses the whole chip: 119.3 -> 119.7 ms per step
+//     when applied to launches with <= 4 splits, 122.4 with <= 8, 126.2 with all.  profiles/round3_fused_splitk.log.)
 struct Plan { int tile; int splits; int streamk; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
 constexpr int SK_GRID = 512;                 // stream-K workgroups: two per CU, all resident
 
