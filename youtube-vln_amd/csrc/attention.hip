@@ -1299,6 +1299,122 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     }
 }
 
+// dK / dV, "w1" form: ONE wave per workgroup and per SIMD owns 32 keys and does all 256 matrix instructions of a (query tile, key tile) pair
+// (unpadded d = 128, fp32 operands; ~340 of the 512 registers a lone wave may use).  The wave-pair form above splits the pair between two
+// waves that meet at two barriers per tile and pass P through LDS, and each of them hashes the dropout mask; here P stays in registers, the
+// mask is hashed once, the LDS fragment reads are batched (PIPE = 8) and nothing waits for anybody.  Private LDS: [Q tile][dO tile][lse row]
+// [delta row] (35 KB: four per CU).  Per query tile t:
+//     wait Q(t)    S = Q.K^T                       wait dO(t)    dP = dO.V^T         P, keep, dS
+//     dK += dS^T.Q   -> DMA Q(t+1)  (travels under the next matmul)      dV += (P o keep)^T.dO   -> DMA dO(t+1)  (travels under the next S)
+// Same arithmetic, same order as attn_bwd_dkv_body: bit-identical results.
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
+    constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* __restrict__ Qs = smem;
+    float* __restrict__ Gs = smem + TS;
+    const int nqt = (a.Tq + 31) >> 5;
+    float* __restrict__ Lrow = smem + 2 * TS;
+    float* __restrict__ Drow = Lrow + nqt * 32;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const int k0 = bx * 32, kj = k0 + l31;
+    const bool kvalid = kj < a.Tk;
+    const int col0 = h * a.d;
+    const int64_t qrow_base = (int64_t)n * a.Tq;
+    const LaneOff lo = make_lane_off<DP>(l31, half);
+    const float* __restrict__ qb = a.q + qrow_base * a.ldq + col0;
+    const float* __restrict__ gb = a.dctx + qrow_base * a.ldo + col0;
+    const int ldq = (int)a.ldq, ldo = (int)a.ldo;
+
+    int gcol[4];          // DMA pieces as in attn_fwd_w1_body
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gcol[u] = 4 * (l31 ^ ((2 * u + half) & 7));
+    const int qlim = (a.Tq - 1) * ldq, glim = (a.Tq - 1) * ldo, qhalf = half * ldq, ghalf = half * ldo;
+    auto qtile = [&](int row0) __attribute__((always_inline)) {
+        const int sbase = row0 * ldq;
+        static_for<16>([&](auto PT) __attribute__((always_inline)) {
+            constexpr int p = decltype(PT)::value;
+            const int off = min(sbase + 2 * p * ldq + qhalf, qlim) + gcol[p & 3];
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qb + (uint32_t)off), (lds_ptr_t)(Qs + p * 256), 16, 0, 0);
+        });
+    };
+    auto gtile = [&](int row0) __attribute__((always_inline)) {
+        const int sbase = row0 * ldo;
+        static_for<16>([&](auto PT) __attribute__((always_inline)) {
+            constexpr int p = decltype(PT)::value;
+            const int off = min(sbase + 2 * p * ldo + ghalf, glim) + gcol[p & 3];
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb + (uint32_t)off), (lds_ptr_t)(Gs + p * 256), 16, 0, 0);
+        });
+    };
+
+    qtile(0);
+    gtile(0);
+    float Kr[DP / 2], Vr[DP / 2];          // (a key past the end repeats the last one: its mask is -inf, so p = 0, and its rows are not stored)
+    load_rowfrag_raw<DP>(Kr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, half);
+    load_rowfrag_raw<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, half);
+    const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
+    const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
+    {          // lse / delta rows of up to 512 queries (launch condition), +inf / 0 past the end
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = lane + 64 * u;
+            if (j < nqt * 32) {
+                Lrow[j] = j < a.Tq ? a.lse[srow + j] : INFINITY;
+                Drow[j] = j < a.Tq ? a.delta[srow + j] : 0.f;
+            }
+        }
+    }
+    f32x16 accV[NJ], accK[NJ];
+#pragma unroll
+    for (int c = 0; c < NJ; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accV[c][r] = 0.f; accK[c][r] = 0.f; }
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr = 0; float ik = 1.f;
+    if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (the last tile is peeled: no conditional DMA issue inside the loop -- control flow there costs register shuffles of both accumulators)
+    auto tile = [&](auto MORE_T, const int t) __attribute__((always_inline)) {
+        constexpr bool more = decltype(MORE_T)::value;
+        const int i0 = t * 32;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // Q(t); dO(t) may still be on its way
+        const f32x16 S = mma_rows<DP, false, false, 8>(Qs, Kr, lo);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // dO(t)
+        const f32x16 dP = mma_rows<DP, false, false, 8>(Gs, Vr, lo);
+        float Pk[16], dS[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
+            const float4 ds = lds4(Drow + i0 + 8 * g + 4 * half);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * g + u;
+                const float p = __expf(score(S[r], a.scale, mk) - lsv[u]);
+                float pk = p, dp = dP[r];
+                if (DROP) {
+                    const bool keep = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + krow(r, half)), key) >= thr;
+                    pk = keep ? p * ik : 0.f;
+                    dp = keep ? dp * ik : 0.f;
+                }
+                Pk[r] = pk;
+                dS[r] = p * (dp - dsv[u]);
+            }
+        }
+        mma_regs_rows<DP, false, false, 8>(accK, dS, Qs, lo);          // dK += dS^T . Q
+        asm volatile("" ::: "memory");
+        if (more) qtile(i0 + 32);
+        mma_regs_rows<DP, false, false, 8>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
+        asm volatile("" ::: "memory");
+        if (more) gtile(i0 + 32);
+    };
+    for (int t = 0; t + 1 < nqt; ++t) tile(std::true_type{}, t);
+    tile(std::false_type{}, nqt - 1);
+    store_rows<DP>(accV, a.dv, a.lddv, (int64_t)n * a.Tk, k0, a.Tk, col0, a.d, l31, half, 1.0f);
+    store_rows<DP>(accK, a.dk, a.lddk, (int64_t)n * a.Tk, k0, a.Tk, col0, a.d, l31, half, a.scale);
+}
+
 // diagnostic: materialise attention_probs (reference returns them when output_all_attention_masks=True)
 __global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
                                                          int64_t ldk, const float* __restrict__ mask, const float* __restrict__ lse,
@@ -1347,6 +1463,8 @@ template <bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dq_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_w1_body<DROP>(a, bx, h, n))); }
 template <int DP, bool DROP, bool BF>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_body<DP, DROP, BF>(a, bx, h, n))); }
+template <bool DROP>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_w1_body<DROP>(a, bx, h, n))); }
 template <int DP, bool DROP, bool BF, int STAGES>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_body<DP, DROP, BF, STAGES>(a, bx, h, n))); }
 #undef YT_ATTN_DECODE
@@ -1552,7 +1670,21 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         else if (w1) hipLaunchKernelGGL(attn_bwd_dq_w1_kernel<false>, dim3((unsigned)total), dim3(64), lds_fwd(dp, maxTk), s, b);
         else YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
     }
-    {
+    // one wave per workgroup and per SIMD (attn_bwd_dkv_w1_body; YTVLN_ATTN_W1_DKV=0: always the wave-pair form): unpadded fp32 heads, lse / delta
+    // rows staged by one wave, and at least two rounds of the 1024 wave slots (a 1.3-round launch -- 3 key tiles x 448 heads -- pays for 2:
+    // there the pair form, whose workgroups are half as long, loses less)
+    static const int w1_dkv_on = env_int("YTVLN_ATTN_W1_DKV", 1);
+    const int64_t w1_waves = (cdiv(b.p[0].Tk, 32) + (np > 1 ? cdiv(b.p[1].Tk, 32) : 0)) * a0.heads * a0.N;
+    if (w1_dkv_on && a0.d == 128 && !a0.bf16 && maxTq <= 512 && (w1_waves >= 2048 || w1_dkv_on == 2)) {
+        b.gx0 = (int)cdiv(b.p[0].Tk, 32);
+        b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32) : 1;
+        b.nb0 = b.gx0 * a0.heads * a0.N;
+        const int64_t total = w1_waves;
+        YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
+        const size_t lds = (size_t)(2 * 32 * 128 + 2 * (int)cdiv(maxTq, 32) * 32) * sizeof(float);
+        if (drop) hipLaunchKernelGGL(attn_bwd_dkv_w1_kernel<true>, dim3((unsigned)total), dim3(64), lds, s, b);
+        else hipLaunchKernelGGL(attn_bwd_dkv_w1_kernel<false>, dim3((unsigned)total), dim3(64), lds, s, b);
+    } else {
         const int npairs = pick_pairs(maxTk, a0.d, a0.bf16), stages = pick_stages(a0.d, npairs, a0.bf16);
         b.gx0 = (int)cdiv(b.p[0].Tk, 32 * npairs);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32 * npairs) : 1;
