@@ -1,6 +1,7 @@
-"""Bit-level comparison of two forms of the attention kernels selected by environment knobs (default: YTVLN_ATTN_W1=0 vs 1).
-Each form runs in its own process (the knobs are read once), on the same seeded inputs; outputs (ctx, lse and, with BWD=1, dq/dk/dv) must be
-bit-identical.  Usage: python tools/attn_form_check.py            (env KNOB=YTVLN_ATTN_W1 A=0 B=1)"""
+"""Comparison of two forms of the attention kernels selected by an environment knob (default: YTVLN_ATTN_W1=0 vs 1; the one-wave-per-SIMD dQ and
+dK/dV kernels: KNOB=YTVLN_ATTN_W1_DQ, and KNOB=YTVLN_ATTN_W1_DKV A=0 B=2 -- 2 forces that form for launches of any size).  Each form runs in its
+own process (the knobs are read once), on the same seeded inputs; outputs (ctx, lse and, with BWD=1, dq/dk/dv) must agree to rounding (the forms
+do the same arithmetic in the same order; hipcc may contract (s - m) * log2(e) differently).  tests/test_attention_forms_gpu.py runs it."""
 import os, sys, math, subprocess, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +57,7 @@ if __name__ == "__main__":
         same = np.array_equal(x, y, equal_nan=True)
         if not same:
             fin = np.isfinite(x) & np.isfinite(y)
-            err = np.abs(x[fin] - y[fin]).max() / max(np.abs(x[fin]).max(), 1e-30)
+            err = np.abs(x[fin] - y[fin]).max() / max(np.abs(x[fin]).max(), 1e-2)      # (inputs are O(1): a tensor that is ~0 up to rounding is compared absolutely)
             nonfin = not np.array_equal(np.isfinite(x), np.isfinite(y))
             # the compiler may contract (s - m) * log2(e) differently in the two forms: differences of a few ulp are not a defect
             ok = err < float(os.environ.get("TOL", "2e-6")) and not nonfin

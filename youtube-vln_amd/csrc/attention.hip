@@ -1006,6 +1006,40 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
 }
 
+// One LDS-DMA stream of the one-wave kernels: 32-row x 128-column tiles of a row-major matrix into a private 16 KB LDS buffer, 16 pieces of two
+// rows each (the Tile<128> layout: granule g of row r at position g ^ (r & 7)).  Per piece of a FULL tile: one add and one 64-bit add on the
+// vector unit, one scalar add for M0 (the per-lane offsets 2p*ld + half*ld + granule column sit in 16 registers, the LDS side is address-
+// space-3 arithmetic -- a generic pointer costs a null check per piece); a tile that crosses the end clamps its rows (four VALU per piece).
+typedef __attribute__((address_space(3))) char lds_char;
+struct W1Stream {
+    const float* __restrict__ base;
+    lds_char* lds;
+    int ld, lim, hl, nrows;
+    int gcol[4], roff[16];
+    __device__ __forceinline__ void init(const float* b, float* ldsbuf, int ld_, int nrows_, int l31, int half) {
+        base = b; lds = (lds_char*)(lds_ptr_t)ldsbuf; ld = ld_; nrows = nrows_; lim = (nrows_ - 1) * ld_; hl = half * ld_;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gcol[u] = 4 * (l31 ^ ((2 * u + half) & 7));
+#pragma unroll
+        for (int p = 0; p < 16; ++p) roff[p] = 2 * p * ld_ + hl + gcol[p & 3];
+    }
+    __device__ __forceinline__ void issue(const int row0) const {
+        const int sbase = row0 * ld;
+        if (row0 + 32 <= nrows) {
+            static_for<16>([&](auto PT) __attribute__((always_inline)) {
+                constexpr int p = decltype(PT)::value;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (uint32_t)(sbase + roff[p])), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
+            });
+        } else {
+            static_for<16>([&](auto PT) __attribute__((always_inline)) {
+                constexpr int p = decltype(PT)::value;
+                const int off = min(sbase + 2 * p * ld + hl, lim) + gcol[p & 3];
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (uint32_t)off), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
+            });
+        }
+    }
+};
+
 // dQ, "w1" form: ONE wave per workgroup and per SIMD (d > 64, fp32 operands), as attn_fwd_w1_body.  The two-wave form pays three rounds of
 // workgroup slots for the 2.19 a 9-tile sequence needs and leaves its LDS fragment reads unpipelined (256 VGPRs); a lone wave has the registers
 // to batch them (mma_rows PIPE = 8), needs no barrier, and 4032 single-tile waves are 3.94 rounds.  Per key tile t:
@@ -1013,6 +1047,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
 //     wait K(t)                      S^T = K(t).Q^T, dS;   dQ += dS.K(t)      -> DMA K(t+1)
 // (every fetch travels under the matrix work of the other buffer; the waits are the wave's own counted vmcnt: 16 pieces of the other tile may
 // stay in flight, except for the last K).  Same arithmetic, same order as attn_bwd_dq_body: bit-identical results.
+// What is left on the table is the start of a round: 1024 waves open together and ask for 80 KB each (~10 us of HBM time, 10-15 % of a wave's
+// life).  Measured and removed (round 3): touching the successor workgroup's fragment rows from the last tile but one (six LDS-DMA dword loads
+// per lane into a dump area) halves the prologue of the waves that guessed their successor right (16k -> 7-10k cycles) and makes the kernel
+// 2.5 % SLOWER -- the touched lines (6 MB per XCD and round) do not survive in a 4 MB L2 and are fetched twice
+// (profiles/round3_attn_w1_dq_prefetch.log).  The fix that remains is a persistent wave that loads its next fragments into spare registers.
 template <bool DROP>
 __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32;
@@ -1038,26 +1077,11 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
     const int ldk = (int)a.ldk, ldv = (int)a.ldv;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
-    int gcol[4];          // DMA pieces as in attn_fwd_w1_body
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gcol[u] = min(4 * (l31 ^ ((2 * u + half) & 7)), a.d - 4);
-    const int klim = (a.Tk - 1) * ldk, vlim = (a.Tk - 1) * ldv, khalf = half * ldk, vhalf = half * ldv;
-    auto ktile = [&](int row0) __attribute__((always_inline)) {
-        const int sbase = row0 * ldk;
-        static_for<16>([&](auto PT) __attribute__((always_inline)) {
-            constexpr int p = decltype(PT)::value;
-            const int off = min(sbase + 2 * p * ldk + khalf, klim) + gcol[p & 3];
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + (uint32_t)off), (lds_ptr_t)(Ks + p * 256), 16, 0, 0);
-        });
-    };
-    auto vtile = [&](int row0) __attribute__((always_inline)) {
-        const int sbase = row0 * ldv;
-        static_for<16>([&](auto PT) __attribute__((always_inline)) {
-            constexpr int p = decltype(PT)::value;
-            const int off = min(sbase + 2 * p * ldv + vhalf, vlim) + gcol[p & 3];
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + (uint32_t)off), (lds_ptr_t)(Vs + p * 256), 16, 0, 0);
-        });
-    };
+    W1Stream ks, vs;
+    ks.init(kb, Ks, ldk, a.Tk, l31, half);
+    vs.init(vb, Vs, ldv, a.Tk, l31, half);
+    auto ktile = [&](int row0) __attribute__((always_inline)) { ks.issue(row0); };
+    auto vtile = [&](int row0) __attribute__((always_inline)) { vs.issue(row0); };
 
     // Prologue, ordered so that the matrix work starts on the first 32 KB: a round of 1024 waves asks for 80 KB each at the same moment
     // (K, V tiles and three register fragments), ~17 us of HBM time during which nothing else runs.  dP^T = V(0).dO^T only needs V(0) and dO;
@@ -1326,27 +1350,11 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
     const float* __restrict__ gb = a.dctx + qrow_base * a.ldo + col0;
     const int ldq = (int)a.ldq, ldo = (int)a.ldo;
 
-    int gcol[4];          // DMA pieces as in attn_fwd_w1_body
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gcol[u] = 4 * (l31 ^ ((2 * u + half) & 7));
-    const int qlim = (a.Tq - 1) * ldq, glim = (a.Tq - 1) * ldo, qhalf = half * ldq, ghalf = half * ldo;
-    auto qtile = [&](int row0) __attribute__((always_inline)) {
-        const int sbase = row0 * ldq;
-        static_for<16>([&](auto PT) __attribute__((always_inline)) {
-            constexpr int p = decltype(PT)::value;
-            const int off = min(sbase + 2 * p * ldq + qhalf, qlim) + gcol[p & 3];
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qb + (uint32_t)off), (lds_ptr_t)(Qs + p * 256), 16, 0, 0);
-        });
-    };
-    auto gtile = [&](int row0) __attribute__((always_inline)) {
-        const int sbase = row0 * ldo;
-        static_for<16>([&](auto PT) __attribute__((always_inline)) {
-            constexpr int p = decltype(PT)::value;
-            const int off = min(sbase + 2 * p * ldo + ghalf, glim) + gcol[p & 3];
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb + (uint32_t)off), (lds_ptr_t)(Gs + p * 256), 16, 0, 0);
-        });
-    };
-
+    W1Stream qs, gs;
+    qs.init(qb, Qs, ldq, a.Tq, l31, half);
+    gs.init(gb, Gs, ldo, a.Tq, l31, half);
+    auto qtile = [&](int row0) __attribute__((always_inline)) { qs.issue(row0); };
+    auto gtile = [&](int row0) __attribute__((always_inline)) { gs.issue(row0); };
     qtile(0);
     gtile(0);
     float Kr[DP / 2], Vr[DP / 2];          // (a key past the end repeats the last one: its mask is -inf, so p = 0, and its rows are not stored)
