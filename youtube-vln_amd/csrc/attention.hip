@@ -112,11 +112,22 @@ __device__ __forceinline__ float4 lds4(const float* __restrict__ p) { return *re
 __device__ __forceinline__ float2 lds2(const float* __restrict__ p) { return *reinterpret_cast<const float2*>(p); }
 
 // per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1 (zero past nrows / past d)
-template <int DP>
+template <int DP, bool BRANCHY = false>
 __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __restrict__ base, int64_t ld, int64_t row_base,
                                              int row, int nrows, int col0, int d, int half) {
+    if constexpr (BRANCHY) {      // the form used until round 3: fewer registers in flight -- kept for the bf16 backward kernels (see below)
+#pragma unroll
+    for (int s4 = 0; s4 < DP / 2; s4 += 4) {
+        const int col = half * (DP / 2) + s4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows && col < d) v = *reinterpret_cast<const float4*>(base + (row_base + row) * ld + col0 + col);
+        R[s4] = v.x; R[s4 + 1] = v.y; R[s4 + 2] = v.z; R[s4 + 3] = v.w;
+    }
+    return;
+    }
     // branch-free: a load under a per-lane condition is followed by a wait at the join, which serialises the DP/8 loads of a fragment (one
-    // memory round trip EACH in every kernel's prologue); clamped addresses + a select keep them all in flight together
+    // memory round trip EACH in every kernel's prologue); clamped addresses + a select keep them all in flight together.  Not for the bf16
+    // backward kernels: with all loads of a fragment live at once they spill (cfg-5 shapes: backward 3.37 -> 4.70 ms; tools/r3_bf16_attn.sh)
     const bool rok = row < nrows;
     const float* __restrict__ rp = base + (row_base + (rok ? row : nrows - 1)) * ld + col0;
     float4 v[DP / 8];
@@ -944,15 +955,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     Tile<DP>::issue(Vs, vb, ldv, 0, a.Tk, a.d, wave, nw, lane);      // V(0) travels while the register fragments are fetched
 
     float Qr[DP / 2], Gr[DP / 2];
-    load_rowfrag<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+    load_rowfrag<DP, BF>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
     float dl;
     if (a.delta_out) {
         // delta = sum_c dO[q][c] * O[q][c] for this lane's query: each half-wave holds half of the head dimension (same association as
         // attn_delta_kernel is not required -- delta is consumed through the same value by both backward kernels)
         float Cr[DP / 2];          // the O fragment: dead before the accumulators come alive; all three fragments' loads fly together
-        load_rowfrag<DP>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
-        load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        load_rowfrag<DP, BF>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        load_rowfrag<DP, BF>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
         float acc = 0.f;
 #pragma unroll
         for (int s4 = 0; s4 < DP / 2; s4 += 4) acc += (Cr[s4] * Gr[s4] + Cr[s4 + 1] * Gr[s4 + 1]) + (Cr[s4 + 2] * Gr[s4 + 2] + Cr[s4 + 3] * Gr[s4 + 3]);
@@ -960,7 +971,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
         if (active && qvalid && half == 0) a.delta_out[sidx] = dl;
     } else {
         dl = qvalid ? a.delta[sidx] : 0.f;
-        load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        load_rowfrag<DP, BF>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     }
     const float lse = qvalid ? a.lse[sidx] : INFINITY;          // a query past the end: p = exp(-inf) = 0
     for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
@@ -1243,8 +1254,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     issue(0);                                   // first Q/dO tile travels while the register fragment and the lse/delta rows are fetched
 
     float Fr[DP / 2];                           // K fragment (S-wave) or V fragment (D-wave)
-    if (role == 0) load_rowfrag<DP>(Fr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
-    else load_rowfrag<DP>(Fr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    if (role == 0) load_rowfrag<DP, BF>(Fr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    else load_rowfrag<DP, BF>(Fr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
     const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
     const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
     for (int j = tid; j < nqt * 32; j += nthr) {
