@@ -1,13 +1,12 @@
 #!/bin/bash
-# step-level ABBA of the one-wave-per-SIMD backward kernels + the GPU tests with them on (the default)
+# step-level ABBA of the one-wave-per-SIMD attention kernels (forward; backward) + the GPU tests with them on (the default)
 mkdir -p gpurun_out
 {
-for v in "1 1" "0 0" "1 0" "0 0" "1 1"; do
+for v in "1 1 1" "0 1 1" "0 0 0" "1 1 1"; do
   set -- $v
-  echo "== YTVLN_ATTN_W1_DQ=$1 YTVLN_ATTN_W1_DKV=$2"
-  YTVLN_ATTN_W1_DQ=$1 YTVLN_ATTN_W1_DKV=$2 timeout 900 python bench.py --steps 10 --warmup 3 --no-variants 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['families']['attention']['ms_per_step'], d['roofline']['families']['attention']['frac'])"
+  echo "== YTVLN_ATTN_W1=$1 YTVLN_ATTN_W1_DQ=$2 YTVLN_ATTN_W1_DKV=$3"
+  YTVLN_ATTN_W1=$1 YTVLN_ATTN_W1_DQ=$2 YTVLN_ATTN_W1_DKV=$3 timeout 900 python bench.py --steps 10 --warmup 3 --no-variants 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['families']['attention']['ms_per_step'], d['roofline']['families']['attention']['frac'])"
 done
-timeout 2400 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; grep "passed\|failed" gpurun_out/gpu_tests.log | tail -2
-KNOB=YTVLN_ATTN_W1_DKV A=0 B=2 BWD=1 timeout 600 python tools/attn_form_check.py 2>&1 | grep -v amdgpu.ids | grep -v "close "
+timeout 2700 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; grep "passed\|failed" gpurun_out/gpu_tests.log | tail -2
 } > gpurun_out/w1_step.log 2>&1
-tail -30 gpurun_out/w1_step.log
+cat gpurun_out/w1_step.log

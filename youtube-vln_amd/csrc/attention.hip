@@ -606,300 +606,6 @@ __device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const in
     if (w == 0 && qvalid && half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
 }
 
-// ---- forward, "w1" form: ONE wave per workgroup, one wave per SIMD (d > 64, fp32 operands) -----------------------------------------
-// The two-wave form above relies on a second wave per SIMD to fill the matrix pipe while the first one runs its softmax; with 9 query tiles
-// per sequence its 2240 workgroups need 2.19 rounds of the 1024 workgroup slots and pay for 3.  Here a workgroup IS a wave with private K / V
-// tiles (33 KB of LDS -> four per CU, one per SIMD; 4032 waves = 3.94 rounds), and the overlap is software-pipelined inside the wave's own
-// instruction stream.  Per key tile t:
-//     phase A : S' = K(t+1) . Q^T   (64 matrix instructions)  ||  VALU: P = dropout(exp(score(t) - m)), row sums
-//     phase B : O += P . V(t)       (64 matrix instructions)  ||  VALU: score(t+1) = S' * scale + mask, row maxima;  DMA: K(t+2) in the first
-//               four steps (the K buffer is free once S' is done), V(t+1) eight rows at a time as P.V releases them
-//     between : the lazy online-softmax reference move (rare; O is at rest)
-// No barriers: the only waits are the wave's own counted vmcnt -- K(t+1) before phase A (the 16 pieces of V issued after it may still be in
-// flight), everything before phase B.  Arithmetic and its order are those of attn_fwd_body, so the two forms agree bit for bit.
-#ifndef W1_VALU_PER_GAP
-#define W1_VALU_PER_GAP 6
-#endif
-#ifndef W1_PROBE      // timing experiments (scratch builds only; results are wrong by construction): 1 no softmax arithmetic, 2 no DMA, 4 no score arithmetic
-#define W1_PROBE 0
-#endif
-template <bool DROP>
-__device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32, HB = 8;
-#ifdef YTVLN_W1_TIMING
-    const uint64_t c_entry = __builtin_amdgcn_s_memtime();
-#endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* __restrict__ Ks = smem;
-    float* __restrict__ Vs = smem + TS;
-    float* __restrict__ Mrow = smem + 2 * TS;
-    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-    const int q0 = bx * 32, qi = q0 + l31;
-    const bool qvalid = qi < a.Tq;
-    const int col0 = h * a.d;
-    const int ntiles = (a.Tk + 31) >> 5;
-    const int64_t krow_base = (int64_t)n * a.Tk;
-    const float* __restrict__ kb = a.k + krow_base * a.ldk + col0;
-    const float* __restrict__ vb = a.v + krow_base * a.ldv + col0;
-    const int ldk = (int)a.ldk, ldv = (int)a.ldv;
-    const LaneOff lo = make_lane_off<DP>(l31, half);
-
-    // DMA piece p of a tile = its rows 2p, 2p+1 (Tile<DP>::issue with the lane-constant parts hoisted): this lane's source is row
-    // min(row0 + 2p + half, nrows - 1), granule l31 ^ ((2p + half) & 7), which only depends on p & 3
-    int gcol[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gcol[u] = min(4 * (l31 ^ ((2 * u + half) & 7)), a.d - 4);
-    const int klim = (a.Tk - 1) * ldk, vlim = (a.Tk - 1) * ldv, khalf = half * ldk, vhalf = half * ldv;
-    // (sbase = row0 * ld: wave-uniform, so everything but one add, one min and the granule offset stays on the scalar unit)
-    auto kpiece = [&](int sbase, auto PT) __attribute__((always_inline)) {
-        constexpr int p = decltype(PT)::value;
-        const int off = min(sbase + 2 * p * ldk + khalf, klim) + gcol[p & 3];
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + (uint32_t)off), (lds_ptr_t)(Ks + p * 256), 16, 0, 0);
-    };
-    auto vpiece = [&](int sbase, auto PT) __attribute__((always_inline)) {
-        constexpr int p = decltype(PT)::value;
-        const int off = min(sbase + 2 * p * ldv + vhalf, vlim) + gcol[p & 3];
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + (uint32_t)off), (lds_ptr_t)(Vs + p * 256), 16, 0, 0);
-    };
-
-    static_for<16>([&](auto PT) __attribute__((always_inline)) { kpiece(0, PT); });      // K(0) travels while Q and the mask row are fetched
-    float Qr[DP / 2];
-    load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
-    for (int j = lane; j < ntiles * 32; j += 64) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
-
-    f32x16 O[NJ];
-#pragma unroll
-    for (int c = 0; c < NJ; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    float P[16], SC[16];
-    f32x16 Sacc;
-    DropKey key = {0, 0, 0, 0};
-    uint32_t thr = 0; float ik = 1.f;
-    const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));
-    if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
-
-    // prologue: S(0) = K(0) . Q^T on its own, then K(1) and V(0) set off, score(0)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    Sacc = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
-    asm volatile("" ::: "memory");
-    if (ntiles > 1) static_for<16>([&](auto PT) __attribute__((always_inline)) { kpiece(32 * ldk, PT); });
-    static_for<16>([&](auto PT) __attribute__((always_inline)) { vpiece(0, PT); });
-    // values of the two half-waves of a query combined with v_permlane32_swap (VALU; a ds_bpermute would put an LDS round trip on the
-    // critical path of every tile): r[0] = {lo, lo}, r[1] = {hi, hi}
-    auto halves_max = [&](float x) __attribute__((always_inline)) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    };
-    auto halves_sum = [&](float x) __attribute__((always_inline)) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    };
-    float mt = -INFINITY;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 mk = lds4(Mrow + 8 * g + 4 * half);
-        SC[4 * g] = score(Sacc[4 * g], a.scale, mk.x); SC[4 * g + 1] = score(Sacc[4 * g + 1], a.scale, mk.y);
-        SC[4 * g + 2] = score(Sacc[4 * g + 2], a.scale, mk.z); SC[4 * g + 3] = score(Sacc[4 * g + 3], a.scale, mk.w);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, SC[r]);
-    mt = halves_max(mt);
-
-    // phase A of tile t (first key j0); MMA: there is a tile t+1 and its K is in LDS
-    auto phase_a = [&](auto MMA_T, const int j0) __attribute__((always_inline)) {
-        constexpr bool MMA = decltype(MMA_T)::value;
-        float4 x[2][HB];
-        if constexpr (MMA) {
-            static_for<HB>([&](auto U) __attribute__((always_inline)) {
-                constexpr int u = decltype(U)::value;
-                x[0][u] = lds4(Ks + lo.rows[u & 7] + (u & ~7) * 4);
-            });
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Sacc[r] = 0.f;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float ps = 0.f;
-        static_for<16>([&](auto G) __attribute__((always_inline)) {
-            constexpr int gi = decltype(G)::value, b = gi / HB, u = gi % HB;
-            if constexpr (MMA) {
-                if constexpr (b == 0) x[1][u] = lds4(Ks + lo.rows[(gi + HB) & 7] + ((gi + HB) & ~7) * 4);
-                Sacc = MFMA(x[b][u].x, Qr[4 * gi], Sacc);
-                Sacc = MFMA(x[b][u].y, Qr[4 * gi + 1], Sacc);
-                Sacc = MFMA(x[b][u].z, Qr[4 * gi + 2], Sacc);
-                Sacc = MFMA(x[b][u].w, Qr[4 * gi + 3], Sacc);
-            }
-            float p;
-            if constexpr ((W1_PROBE & 1) != 0) {
-                p = SC[gi];
-            } else {
-            p = __expf(SC[gi] - m);
-            ps += p;
-            if (DROP) {
-                const uint32_t bits = attn_drop_hash((uint32_t)(j0 + krow(gi, half)), dlo, key);
-                p = bits >= thr ? p * ik : 0.f;
-            }
-            }
-            if constexpr (MMA) asm volatile("" : "+v"(p));      // finished HERE, under this step's matrix instructions (not sunk to its use in phase B)
-            P[gi] = p;
-            if constexpr (MMA) {
-                // the element's ~22 VALU instructions spread over the four gaps between the step's (dependent, 64-cycle) matrix instructions:
-                // a gap holds ~14 plain VALU issue slots, a clump of 20+ behind one matrix instruction delays the next one
-                if constexpr (b == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, W1_VALU_PER_GAP, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-        l += halves_sum(ps);
-    };
-    // phase B of tile t; NEXT: there is a tile t+1 (its raw scores are in Sacc) and its V is fetched; KLOAD: there is a tile t+2, its K is fetched
-    auto phase_b = [&](auto NEXT_T, auto KLOAD_T, const int j0) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(NEXT_T)::value, KLOAD = decltype(KLOAD_T)::value;
-        float v[2][HB][NJ];
-        auto rd = [&](auto R, auto BUF) __attribute__((always_inline)) {
-            constexpr int r = decltype(R)::value, bf = decltype(BUF)::value;
-            const float4 t4 = lds4(Vs + lo.brow[r & 3] + 8 * (r >> 2) * DP);
-            v[bf][r % HB][0] = t4.x; v[bf][r % HB][1] = t4.y; v[bf][r % HB][2] = t4.z; v[bf][r % HB][3] = t4.w;
-        };
-        static_for<HB>([&](auto R) __attribute__((always_inline)) { rd(R, std::integral_constant<int, 0>{}); });
-        float4 mk[4];
-        if constexpr (NEXT) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) mk[g] = lds4(Mrow + j0 + 32 + 8 * g + 4 * half);
-            mt = -INFINITY;
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<16>([&](auto R) __attribute__((always_inline)) {
-            constexpr int r = decltype(R)::value, b = r / HB, u = r % HB;
-            if constexpr (b == 0) rd(std::integral_constant<int, r + HB>{}, std::integral_constant<int, 1>{});
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) O[j] = MFMA(P[r], v[b][u][j], O[j]);
-            if constexpr (NEXT) {
-                // (values laundered through an empty asm: arithmetic that only depends on them cannot float above this step -- instruction
-                // selection is otherwise free to put all of the phase's address and score arithmetic in front of its first matrix instruction)
-                int kl = (j0 + 64) * ldk, vl = (j0 + 32) * ldv;
-                asm volatile("" : "+s"(kl), "+s"(vl));
-                if constexpr (r < 8) {          // scores of tile t+1, two per step; their maxima are complete (and exchanged) at step 8
-                    static_for<2>([&](auto I) __attribute__((always_inline)) {
-                        constexpr int e = 2 * r + decltype(I)::value;
-                        const float mkr = (e & 3) == 0 ? mk[e >> 2].x : (e & 3) == 1 ? mk[e >> 2].y : (e & 3) == 2 ? mk[e >> 2].z : mk[e >> 2].w;
-                        if constexpr ((W1_PROBE & 4) == 0) {
-                        float sraw = Sacc[e];
-                        asm volatile("" : "+v"(sraw));
-                        SC[e] = score(sraw, a.scale, mkr);
-                        mt = fmaxf(mt, SC[e]);
-                        }
-                    });
-                    if constexpr (KLOAD && (W1_PROBE & 2) == 0) {      // K(t+2): the K buffer has been free since phase A ended
-                        kpiece(kl, std::integral_constant<int, 2 * r>{});
-                        kpiece(kl, std::integral_constant<int, 2 * r + 1>{});
-                    }
-                }
-                if constexpr (r == 8) mt = halves_max(mt);
-                // V(t+1): piece q = rows 2q, 2q+1 belongs to the 8-row group q >> 2, which P.V has consumed after step 4 * (q >> 2) + 3
-                if constexpr (r >= 4 && (W1_PROBE & 2) == 0) {
-                    asm volatile("" ::: "memory");
-                    vpiece(vl, std::integral_constant<int, r - 4>{});
-                }
-                if constexpr (r == 15 && (W1_PROBE & 2) == 0) static_for<4>([&](auto I) __attribute__((always_inline)) {
-                    vpiece(vl, std::integral_constant<int, 12 + decltype(I)::value>{}); });
-                // the step's VALU / DMA work in the gaps between its four matrix instructions (see phase A)
-                if constexpr (b == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-
-    // the lazy online-softmax reference move (see attn_fwd_body); mt: maxima of the tile about to be exponentiated, both half-waves combined
-    auto move_reference = [&]() __attribute__((always_inline)) {
-        if (__any(mt > m + RESCALE_THR)) {
-            const float mn = fmaxf(m, mt);
-            const float alpha = __expf(m - mn);
-            l *= alpha;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float ar = __shfl(alpha, krow(r, half) + 32 * half, 64);
-#pragma unroll
-                for (int c = 0; c < NJ; ++c) O[c][r] *= ar;
-            }
-        }
-    };
-#ifdef YTVLN_W1_TIMING
-    uint64_t tw_a = 0, tp_a = 0, tw_b = 0, tp_b = 0, tr = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
-    const uint64_t cstart = c0;
-#define W1_LAP(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
-#else
-#define W1_LAP(acc) do {} while (0)
-#endif
-    // Waiting for K(t+1): the pieces issued after its last one are V(t)'s pieces 3 .. 15 (phase B interleaves them; after the prologue all 16
-    // follow, and the same count then also waits for three pieces of V(0), which costs nothing).
-    // The last two tiles are peeled: one form of each phase per loop body, no register shuffles at control-flow joins.
-    for (int t = 0; t + 2 < ntiles; ++t) {
-        const int j0 = t * 32;
-        move_reference();
-        W1_LAP(tr);
-        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // K(t+1)
-        W1_LAP(tw_a);
-        phase_a(std::true_type{}, j0);
-        W1_LAP(tp_a);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // V(t)
-        W1_LAP(tw_b);
-        phase_b(std::true_type{}, std::true_type{}, j0);
-        W1_LAP(tp_b);
-    }
-#ifdef YTVLN_W1_TIMING
-    const uint64_t c_loop_end = __builtin_amdgcn_s_memtime();
-#endif
-#undef W1_LAP
-    if (ntiles > 1) {
-        const int j0 = (ntiles - 2) * 32;
-        move_reference();
-        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        phase_a(std::true_type{}, j0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        phase_b(std::true_type{}, std::false_type{}, j0);
-    }
-    move_reference();
-    phase_a(std::false_type{}, (ntiles - 1) * 32);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    phase_b(std::false_type{}, std::false_type{}, (ntiles - 1) * 32);
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float ir = __shfl(inv, krow(r, half) + 32 * half, 64);
-#pragma unroll
-        for (int c = 0; c < NJ; ++c) O[c][r] *= ir;
-    }
-    store_rows<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, 1.0f);
-    if (qvalid && half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
-#ifdef YTVLN_W1_TIMING
-    {
-        const uint64_t c_store = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint64_t c_end = __builtin_amdgcn_s_memtime();
-        if ((blockIdx.x == gridDim.x / 2 + 3 || blockIdx.x == 5 || blockIdx.x == gridDim.x - 9) && lane == 0)
-            printf("w1 timing (cycles, wave %d, %d tiles): prologue %llu | loop (ntiles-2) %llu: reference %llu  wait K %llu  phase A %llu  wait V %llu  phase B %llu | "
-                   "last two tiles + 1/l + stores issued %llu | stores drained %llu | total %llu\n",
-                   (int)blockIdx.x, ntiles, (unsigned long long)(cstart - c_entry), (unsigned long long)(c_loop_end - cstart), (unsigned long long)tr,
-                   (unsigned long long)tw_a, (unsigned long long)tp_a, (unsigned long long)tw_b, (unsigned long long)tp_b,
-                   (unsigned long long)(c_store - c_loop_end), (unsigned long long)(c_end - c_store), (unsigned long long)(c_end - c_entry));
-    }
-#endif
-}
-
 // delta[n,h,q] = sum_c dctx[n,q,h*d+c] * ctx[n,q,h*d+c]
 // LG lanes (a power of two >= d/4) share one (row, head) segment: every lane moves one 16-byte piece of ctx and dctx, so a wave
 // sweeps 1 KiB of each row contiguously; the segment sum is a log2(LG)-step shuffle reduction (fixed order -> deterministic).
@@ -1050,6 +756,141 @@ struct W1Stream {
         }
     }
 };
+
+// forward, "w1" form: ONE wave per workgroup and per SIMD (unpadded d = 128, fp32 operands, sequences <= 512), written straight down like the
+// backward kernels below -- S = K.Q^T, then the softmax, then O += P.V; fragment reads batched inside each matmul (PIPE = 8), a whole tile of
+// LDS-DMA issued behind the matmul that frees its buffer, no barrier, the wave's own counted vmcnt as the only waits.  4032 single-tile waves are
+// 3.94 rounds of the 1024 wave slots (private 33 KB of LDS -> four per CU); the two-wave form pays for its second wave with two barriers per
+// tile and relies on the d-split trick for its half-empty workgroups.  Image self-attention (56 pairs) 262 -> 224 us, co-attention pair
+// 181 -> 163 us.  Round 3 also built and measured a software-pipelined one-wave form (softmax of tile t written between the matrix instructions
+// of S(t+1), DMA pieces spread over the P.V steps; ISA checked): 246 us -- a wave's VALU time is NOT hidden under its own matrix instructions,
+// the times add (profiles/round3_attn_w1_probes.log), so the interleaving only added control overhead and was removed.
+// Same arithmetic, same order as attn_fwd_body: the forms agree to rounding (tests/test_attention_forms_gpu.py).
+template <bool DROP>
+__device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
+    constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* __restrict__ Ks = smem;
+    float* __restrict__ Vs = smem + TS;
+    float* __restrict__ Mrow = smem + 2 * TS;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const int q0 = bx * 32, qi = q0 + l31;
+    const bool qvalid = qi < a.Tq;
+    const int col0 = h * a.d;
+    const int ntiles = (a.Tk + 31) >> 5;
+    const int64_t krow_base = (int64_t)n * a.Tk;
+    const LaneOff lo = make_lane_off<DP>(l31, half);
+    W1Stream ks, vs;
+    ks.init(a.k + krow_base * a.ldk + col0, Ks, (int)a.ldk, a.Tk, l31, half);
+    vs.init(a.v + krow_base * a.ldv + col0, Vs, (int)a.ldv, a.Tk, l31, half);
+
+    int64_t rng_seed = 0, rng_ctr = 0;          // small loads first, consumed in the first tile (see attn_bwd_dq_w1_body)
+    if (DROP) { rng_seed = a.rng[0]; rng_ctr = a.rng[1]; }
+    const int mrows = ntiles * 32;
+    float mreg[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int jj = lane + 64 * u;
+        const float mv = a.mask ? a.mask[krow_base + min(jj, a.Tk - 1)] : 0.f;
+        mreg[u] = jj < a.Tk ? mv : -INFINITY;
+    }
+    ks.issue(0);
+    vs.issue(0);
+    float Qr[DP / 2];          // (a query past the end repeats the last one: its row of O and its lse are not stored)
+    load_rowfrag_raw<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, half);
+
+    f32x16 O[NJ];
+#pragma unroll
+    for (int c = 0; c < NJ; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr = 0; float ik = 1.f;
+    const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));
+    if (DROP) { thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
+    auto halves_max = [&](float x) __attribute__((always_inline)) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
+    auto halves_sum = [&](float x) __attribute__((always_inline)) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+
+    auto tile = [&](auto FIRST_T, auto MORE_T, const int t) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
+        const int j0 = t * 32;
+        // K(t); V(t) (16 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
+        if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        const f32x16 S = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
+        asm volatile("" ::: "memory");
+        if (more) ks.issue(j0 + 32);
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lane + 64 * u < mrows) Mrow[lane + 64 * u] = mreg[u];
+            if (DROP) key = drop_key_of((uint64_t)rng_seed, (uint64_t)rng_ctr, a.site);
+        }
+        float P[16];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 mk = lds4(Mrow + j0 + 8 * g + 4 * half);
+            P[4 * g] = score(S[4 * g], a.scale, mk.x); P[4 * g + 1] = score(S[4 * g + 1], a.scale, mk.y);
+            P[4 * g + 2] = score(S[4 * g + 2], a.scale, mk.z); P[4 * g + 3] = score(S[4 * g + 3], a.scale, mk.w);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, P[r]);
+        mt = halves_max(mt);
+        if (__any(mt > m + RESCALE_THR)) {          // the lazy online-softmax reference move (see attn_fwd_body)
+            const float mn = fmaxf(m, mt);
+            const float alpha = __expf(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ar = __shfl(alpha, krow(r, half) + 32 * half, 64);
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) O[c][r] *= ar;
+            }
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
+        l += halves_sum(ps);
+        if (DROP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t bits = attn_drop_hash((uint32_t)(j0 + krow(r, half)), dlo, key);
+                P[r] = bits >= thr ? P[r] * ik : 0.f;
+            }
+        }
+        // V(t); K(t+1), if there is one, may still be on its way
+        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mma_regs_rows<DP, false, false, 8>(O, P, Vs, lo);
+        asm volatile("" ::: "memory");
+        if (more) vs.issue(j0 + 32);
+    };
+    if (ntiles == 1) {
+        tile(std::true_type{}, std::false_type{}, 0);
+    } else {
+        tile(std::true_type{}, std::true_type{}, 0);
+        for (int t = 1; t + 1 < ntiles; ++t) tile(std::false_type{}, std::true_type{}, t);
+        tile(std::false_type{}, std::false_type{}, ntiles - 1);
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float ir = __shfl(inv, krow(r, half) + 32 * half, 64);
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) O[c][r] *= ir;
+    }
+    store_rows<DP>(O, a.out, a.ldo, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, 1.0f);
+    if (qvalid && half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
+}
 
 // dQ, "w1" form: ONE wave per workgroup and per SIMD (d > 64, fp32 operands), as attn_fwd_w1_body.  The two-wave form pays three rounds of
 // workgroup slots for the 2.19 a 9-tile sequence needs and leaves its LDS fragment reads unpipelined (256 VGPRs); a lone wave has the registers
@@ -1612,9 +1453,9 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
         drop = drop || b.p[i].p_drop > 0.f;
         maxTq = std::max(maxTq, b.p[i].Tq); maxTk = std::max(maxTk, b.p[i].Tk);
     }
-    // one wave per workgroup and per SIMD (attn_fwd_w1_body): YTVLN_ATTN_W1=1
-    static const int w1_on = env_int("YTVLN_ATTN_W1", 0);
-    if (w1_on && dp == 128 && !a0.bf16) {
+    // one wave per workgroup and per SIMD (attn_fwd_w1_body); YTVLN_ATTN_W1=0: the two-wave form everywhere
+    static const int w1_on = env_int("YTVLN_ATTN_W1", 1);
+    if (w1_on && a0.d == 128 && !a0.bf16 && maxTk <= 512) {
         b.gx0 = (int)cdiv(b.p[0].Tq, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
