@@ -723,34 +723,38 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
 }
 
-// One LDS-DMA stream of the one-wave kernels: 32-row x 128-column tiles of a row-major matrix into a private 16 KB LDS buffer, 16 pieces of two
-// rows each (the Tile<128> layout: granule g of row r at position g ^ (r & 7)).  Per piece of a FULL tile: one add and one 64-bit add on the
-// vector unit, one scalar add for M0 (the per-lane offsets 2p*ld + half*ld + granule column sit in 16 registers, the LDS side is address-
-// space-3 arithmetic -- a generic pointer costs a null check per piece); a tile that crosses the end clamps its rows (four VALU per piece).
+// One LDS-DMA stream of the one-wave kernels: 32-row x DP-column tiles of a row-major matrix into a private LDS buffer, DP/8 pieces of 1 KiB
+// (256/DP rows each; the Tile<DP> layout: granule g of row r at position g ^ (r & 7)).  Per piece of a FULL tile: one add and one 64-bit add on
+// the vector unit, one scalar move for M0 (the per-lane offsets row * ld + granule column are lane constants, the LDS side is address-space-3
+// arithmetic -- a generic pointer costs a null check per piece); a tile that crosses the end clamps its rows (four VALU per piece).
+// Unpadded heads only (d == DP: no column clamp).
 typedef __attribute__((address_space(3))) char lds_char;
+template <int DP>
 struct W1Stream {
+    static constexpr int PIECES = DP / 8, RPP = 256 / DP, LPR = DP / 4, NV = 8 / RPP;      // rows per piece, lanes per row, granule-column variants
     const float* __restrict__ base;
     lds_char* lds;
-    int ld, lim, hl, nrows;
-    int gcol[4], roff[16];
-    __device__ __forceinline__ void init(const float* b, float* ldsbuf, int ld_, int nrows_, int l31, int half) {
-        base = b; lds = (lds_char*)(lds_ptr_t)ldsbuf; ld = ld_; nrows = nrows_; lim = (nrows_ - 1) * ld_; hl = half * ld_;
+    int ld, lim, lrow_ld, nrows;
+    int gcol[NV], roff[PIECES];
+    __device__ __forceinline__ void init(const float* b, float* ldsbuf, int ld_, int nrows_, int lane) {
+        const int lr = lane / LPR, pos = lane % LPR;          // this lane's row inside a piece, its 16-byte position inside the row
+        base = b; lds = (lds_char*)(lds_ptr_t)ldsbuf; ld = ld_; nrows = nrows_; lim = (nrows_ - 1) * ld_; lrow_ld = lr * ld_;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) gcol[u] = 4 * (l31 ^ ((2 * u + half) & 7));
+        for (int u = 0; u < NV; ++u) gcol[u] = 4 * (pos ^ ((RPP * u + lr) & 7));
 #pragma unroll
-        for (int p = 0; p < 16; ++p) roff[p] = 2 * p * ld_ + hl + gcol[p & 3];
+        for (int p = 0; p < PIECES; ++p) roff[p] = RPP * p * ld_ + lrow_ld + gcol[p % NV];
     }
     __device__ __forceinline__ void issue(const int row0) const {
         const int sbase = row0 * ld;
         if (row0 + 32 <= nrows) {
-            static_for<16>([&](auto PT) __attribute__((always_inline)) {
+            static_for<PIECES>([&](auto PT) __attribute__((always_inline)) {
                 constexpr int p = decltype(PT)::value;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (uint32_t)(sbase + roff[p])), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
             });
         } else {
-            static_for<16>([&](auto PT) __attribute__((always_inline)) {
+            static_for<PIECES>([&](auto PT) __attribute__((always_inline)) {
                 constexpr int p = decltype(PT)::value;
-                const int off = min(sbase + 2 * p * ld + hl, lim) + gcol[p & 3];
+                const int off = min(sbase + RPP * p * ld + lrow_ld, lim) + gcol[p % NV];
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (uint32_t)off), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
             });
         }
@@ -766,9 +770,9 @@ struct W1Stream {
 // of S(t+1), DMA pieces spread over the P.V steps; ISA checked): 246 us -- a wave's VALU time is NOT hidden under its own matrix instructions,
 // the times add (profiles/round3_attn_w1_probes.log), so the interleaving only added control overhead and was removed.
 // Same arithmetic, same order as attn_fwd_body: the forms agree to rounding (tests/test_attention_forms_gpu.py).
-template <bool DROP>
+template <int DP, bool DROP>
 __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32;
+    constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ Ks = smem;
     float* __restrict__ Vs = smem + TS;
@@ -780,9 +784,9 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
     const int ntiles = (a.Tk + 31) >> 5;
     const int64_t krow_base = (int64_t)n * a.Tk;
     const LaneOff lo = make_lane_off<DP>(l31, half);
-    W1Stream ks, vs;
-    ks.init(a.k + krow_base * a.ldk + col0, Ks, (int)a.ldk, a.Tk, l31, half);
-    vs.init(a.v + krow_base * a.ldv + col0, Vs, (int)a.ldv, a.Tk, l31, half);
+    W1Stream<DP> ks, vs;
+    ks.init(a.k + krow_base * a.ldk + col0, Ks, (int)a.ldk, a.Tk, lane);
+    vs.init(a.v + krow_base * a.ldv + col0, Vs, (int)a.ldv, a.Tk, lane);
 
     int64_t rng_seed = 0, rng_ctr = 0;          // small loads first, consumed in the first tile (see attn_bwd_dq_w1_body)
     if (DROP) { rng_seed = a.rng[0]; rng_ctr = a.rng[1]; }
@@ -904,9 +908,9 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
 // per lane into a dump area) halves the prologue of the waves that guessed their successor right (16k -> 7-10k cycles) and makes the kernel
 // 2.5 % SLOWER -- the touched lines (6 MB per XCD and round) do not survive in a 4 MB L2 and are fetched twice
 // (profiles/round3_attn_w1_dq_prefetch.log).  The fix that remains is a persistent wave that loads its next fragments into spare registers.
-template <bool DROP>
+template <int DP, bool DROP>
 __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32;
+    constexpr int TS = 32 * DP, NJ = DP / 32;
 #ifdef YTVLN_W1_TIMING
     const uint64_t c_entry = __builtin_amdgcn_s_memtime();
     uint64_t tw1 = 0, tp1 = 0, ti1 = 0, tw2 = 0, tp2 = 0, tv = 0, tp3 = 0, ti3 = 0, c0, c1;
@@ -929,9 +933,9 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
     const int ldk = (int)a.ldk, ldv = (int)a.ldv;
     const LaneOff lo = make_lane_off<DP>(l31, half);
 
-    W1Stream ks, vs;
-    ks.init(kb, Ks, ldk, a.Tk, l31, half);
-    vs.init(vb, Vs, ldv, a.Tk, l31, half);
+    W1Stream<DP> ks, vs;
+    ks.init(kb, Ks, ldk, a.Tk, lane);
+    vs.init(vb, Vs, ldv, a.Tk, lane);
     auto ktile = [&](int row0) __attribute__((always_inline)) { ks.issue(row0); };
     auto vtile = [&](int row0) __attribute__((always_inline)) { vs.issue(row0); };
 
@@ -1183,9 +1187,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
 //     wait Q(t)    S = Q.K^T                       wait dO(t)    dP = dO.V^T         P, keep, dS
 //     dK += dS^T.Q   -> DMA Q(t+1)  (travels under the next matmul)      dV += (P o keep)^T.dO   -> DMA dO(t+1)  (travels under the next S)
 // Same arithmetic, same order as attn_bwd_dkv_body: bit-identical results.
-template <bool DROP>
+template <int DP, bool DROP>
 __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
-    constexpr int DP = 128, TS = 32 * DP, NJ = DP / 32;
+    constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ Qs = smem;
     float* __restrict__ Gs = smem + TS;
@@ -1202,9 +1206,9 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
     const float* __restrict__ gb = a.dctx + qrow_base * a.ldo + col0;
     const int ldq = (int)a.ldq, ldo = (int)a.ldo;
 
-    W1Stream qs, gs;
-    qs.init(qb, Qs, ldq, a.Tq, l31, half);
-    gs.init(gb, Gs, ldo, a.Tq, l31, half);
+    W1Stream<DP> qs, gs;
+    qs.init(qb, Qs, ldq, a.Tq, lane);
+    gs.init(gb, Gs, ldo, a.Tq, lane);
     auto qtile = [&](int row0) __attribute__((always_inline)) { qs.issue(row0); };
     auto gtile = [&](int row0) __attribute__((always_inline)) { gs.issue(row0); };
     qtile(0);
@@ -1317,14 +1321,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnLaunch b) { 
 template <int PROBE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_probe_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<128, true, false, PROBE>(a, bx, h, n))); }
 #endif
-template <bool DROP>
-__global__ __launch_bounds__(64) void attn_fwd_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_w1_body<DROP>(a, bx, h, n))); }
-template <bool DROP>
-__global__ __launch_bounds__(64) void attn_bwd_dq_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_w1_body<DROP>(a, bx, h, n))); }
+template <int DP, bool DROP>
+__global__ __launch_bounds__(64) void attn_fwd_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_w1_body<DP, DROP>(a, bx, h, n))); }
+template <int DP, bool DROP>
+__global__ __launch_bounds__(64) void attn_bwd_dq_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_w1_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP, bool BF>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_body<DP, DROP, BF>(a, bx, h, n))); }
-template <bool DROP>
-__global__ __launch_bounds__(64) void attn_bwd_dkv_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_w1_body<DROP>(a, bx, h, n))); }
+template <int DP, bool DROP>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_w1_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP, bool BF, int STAGES>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_body<DP, DROP, BF, STAGES>(a, bx, h, n))); }
 #undef YT_ATTN_DECODE
@@ -1455,15 +1459,26 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
     }
     // one wave per workgroup and per SIMD (attn_fwd_w1_body); YTVLN_ATTN_W1=0: the two-wave form everywhere
     static const int w1_on = env_int("YTVLN_ATTN_W1", 1);
-    if (w1_on && a0.d == 128 && !a0.bf16 && maxTk <= 512) {
+    static const int w1_d64 = env_int("YTVLN_ATTN_W1_D64", 1);          // 0: the one-wave kernels only for d = 128 (all three kernels)
+    const bool w1_dim = a0.d == 128 || (a0.d == 64 && w1_d64);             // unpadded heads the one-wave kernels are instantiated for
+    if (w1_on && w1_dim && !a0.bf16 && maxTk <= 512) {
         b.gx0 = (int)cdiv(b.p[0].Tq, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
         const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
         YT_REQUIRE(total < (1ll << 31), "attn_fwd: grid too large");
         for (int i = 0; i < np; ++i) b.p[i].dsplit = 0;
-        if (drop) hipLaunchKernelGGL(attn_fwd_w1_kernel<true>, dim3((unsigned)total), dim3(64), lds_fwd(dp, maxTk), s, b);
-        else hipLaunchKernelGGL(attn_fwd_w1_kernel<false>, dim3((unsigned)total), dim3(64), lds_fwd(dp, maxTk), s, b);
+#define YT_W1(KERNEL, LDS)                                                                                             \
+    do {                                                                                                              \
+        if (a0.d == 128) {                                                                                            \
+            if (drop) hipLaunchKernelGGL((KERNEL<128, true>), dim3((unsigned)total), dim3(64), LDS, s, b);            \
+            else hipLaunchKernelGGL((KERNEL<128, false>), dim3((unsigned)total), dim3(64), LDS, s, b);                \
+        } else {                                                                                                      \
+            if (drop) hipLaunchKernelGGL((KERNEL<64, true>), dim3((unsigned)total), dim3(64), LDS, s, b);             \
+            else hipLaunchKernelGGL((KERNEL<64, false>), dim3((unsigned)total), dim3(64), LDS, s, b);                 \
+        }                                                                                                             \
+    } while (0)
+        YT_W1(attn_fwd_w1_kernel, lds_fwd(dp, maxTk));
         YT_LAUNCH_CHECK("attn_fwd (w1)");
         return 0;
     }
@@ -1519,31 +1534,34 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
     }
     {
         static const int w1_on = env_int("YTVLN_ATTN_W1_DQ", 1);          // one wave per workgroup and per SIMD (attn_bwd_dq_w1_body); 0: the two-wave form
-        const bool w1 = w1_on && a0.d == 128 && !a0.bf16 && !delta_kernel && maxTk <= 512;      // (unpadded heads, delta produced here, mask row in registers)
+        static const int w1_d64 = env_int("YTVLN_ATTN_W1_D64", 1);
+        const bool w1 = w1_on && (a0.d == 128 || (a0.d == 64 && w1_d64)) && !a0.bf16 && !delta_kernel && maxTk <= 512;      // (unpadded heads, delta produced here, mask row in registers)
         const int nw = w1 ? 1 : pick_waves(maxTq, a0.d);
         b.gx0 = (int)cdiv(b.p[0].Tq, 32 * nw);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32 * nw) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
         const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
         YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
-        if (w1 && drop) hipLaunchKernelGGL(attn_bwd_dq_w1_kernel<true>, dim3((unsigned)total), dim3(64), lds_fwd(dp, maxTk), s, b);
-        else if (w1) hipLaunchKernelGGL(attn_bwd_dq_w1_kernel<false>, dim3((unsigned)total), dim3(64), lds_fwd(dp, maxTk), s, b);
+        if (w1) YT_W1(attn_bwd_dq_w1_kernel, lds_fwd(dp, maxTk));
         else YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
     }
     // one wave per workgroup and per SIMD (attn_bwd_dkv_w1_body; YTVLN_ATTN_W1_DKV=0: always the wave-pair form): unpadded fp32 heads, lse / delta
     // rows staged by one wave, and at least two rounds of the 1024 wave slots (a 1.3-round launch -- 3 key tiles x 448 heads -- pays for 2:
     // there the pair form, whose workgroups are half as long, loses less)
     static const int w1_dkv_on = env_int("YTVLN_ATTN_W1_DKV", 1);
+    static const int w1_dkv_d64 = env_int("YTVLN_ATTN_W1_D64", 1);
     const int64_t w1_waves = (cdiv(b.p[0].Tk, 32) + (np > 1 ? cdiv(b.p[1].Tk, 32) : 0)) * a0.heads * a0.N;
-    if (w1_dkv_on && a0.d == 128 && !a0.bf16 && maxTq <= 512 && (w1_waves >= 2048 || w1_dkv_on == 2)) {
+    const int64_t w1_slots = a0.d == 128 ? 1024 : 2048;          // (d = 64: 17 KB of LDS and < 256 registers per wave -> two per SIMD)
+    const bool w1_fill = w1_waves * 100 >= cdiv(w1_waves, w1_slots) * w1_slots * 85;      // the last round at least ~85 % useful overall
+    if (w1_dkv_on && (a0.d == 128 || (a0.d == 64 && w1_dkv_d64)) && !a0.bf16 && maxTq <= 512 && (w1_fill || w1_dkv_on == 2)) {
         b.gx0 = (int)cdiv(b.p[0].Tk, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
         const int64_t total = w1_waves;
         YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
-        const size_t lds = (size_t)(2 * 32 * 128 + 2 * (int)cdiv(maxTq, 32) * 32) * sizeof(float);
-        if (drop) hipLaunchKernelGGL(attn_bwd_dkv_w1_kernel<true>, dim3((unsigned)total), dim3(64), lds, s, b);
-        else hipLaunchKernelGGL(attn_bwd_dkv_w1_kernel<false>, dim3((unsigned)total), dim3(64), lds, s, b);
+        const size_t lds = (size_t)(2 * 32 * dp + 2 * (int)cdiv(maxTq, 32) * 32) * sizeof(float);
+        YT_W1(attn_bwd_dkv_w1_kernel, lds);
+#undef YT_W1
     } else {
         const int npairs = pick_pairs(maxTk, a0.d, a0.bf16), stages = pick_stages(a0.d, npairs, a0.bf16);
         b.gx0 = (int)cdiv(b.p[0].Tk, 32 * npairs);
