@@ -723,6 +723,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
 }
 
+// counted wait of the one-wave kernels: at most N vector-memory operations (LDS-DMA pieces, fragment loads) still in flight.  The counts are
+// multiples of a tile's DP/8 pieces (= a fragment's DP/8 loads): a literal 16 is right for DP = 128 only.
+template <int N>
+__device__ __forceinline__ void w1_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // One LDS-DMA stream of the one-wave kernels: 32-row x DP-column tiles of a row-major matrix into a private LDS buffer, DP/8 pieces of 1 KiB
 // (256/DP rows each; the Tile<DP> layout: granule g of row r at position g ^ (r & 7)).  Per piece of a FULL tile: one add and one 64-bit add on
 // the vector unit, one scalar move for M0 (the per-lane offsets row * ld + granule column are lane constants, the LDS side is address-space-3
@@ -825,9 +830,9 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
     auto tile = [&](auto FIRST_T, auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
         const int j0 = t * 32;
-        // K(t); V(t) (16 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
+        // K(t); V(t) (DP/8 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else w1_wait<DP / 8>();
         const f32x16 S = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
         asm volatile("" ::: "memory");
         if (more) ks.issue(j0 + 32);
@@ -872,7 +877,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
             }
         }
         // V(t); K(t+1), if there is one, may still be on its way
-        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mma_regs_rows<DP, false, false, 8>(O, P, Vs, lo);
         asm volatile("" ::: "memory");
@@ -901,7 +906,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
 // to batch them (mma_rows PIPE = 8), needs no barrier, and 4032 single-tile waves are 3.94 rounds.  Per key tile t:
 //     wait V(t)                      dP^T = V(t).dO^T      -> DMA V(t+1)
 //     wait K(t)                      S^T = K(t).Q^T, dS;   dQ += dS.K(t)      -> DMA K(t+1)
-// (every fetch travels under the matrix work of the other buffer; the waits are the wave's own counted vmcnt: 16 pieces of the other tile may
+// (every fetch travels under the matrix work of the other buffer; the waits are the wave's own counted vmcnt: the DP/8 pieces of the other tile may
 // stay in flight, except for the last K).  Same arithmetic, same order as attn_bwd_dq_body: bit-identical results.
 // What is left on the table is the start of a round: 1024 waves open together and ask for 80 KB each (~10 us of HBM time, 10-15 % of a wave's
 // life).  Measured and removed (round 3): touching the successor workgroup's fragment rows from the last tile but one (six LDS-DMA dword loads
@@ -977,15 +982,15 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
     c0 = __builtin_amdgcn_s_memtime();
     const uint64_t cstart = c0;
 #endif
-    // one key tile; FIRST: tile 0, with the Q fragment (16 loads) and, when this kernel also produces delta, the O fragment (16 more) still in
+    // one key tile; FIRST: tile 0, with the Q fragment (DP/8 loads) and, when this kernel also produces delta, the O fragment (DP/8 more) still in
     // the queue behind K(0)
     auto tile = [&](auto FIRST_T, const int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_T)::value;
         const int j0 = t * 32;
         const bool more = t + 1 < ntiles;
-        // V(t).  Behind it in the queue: K(t) (16 pieces); in the first tile K(0) and dO (needed now as well), then Q and O
-        if (FIRST) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // V(t).  Behind it in the queue: K(t) (DP/8 pieces); in the first tile K(0) and dO (needed now as well), then Q and O
+        if (FIRST) w1_wait<2 * (DP / 8)>();
+        else w1_wait<DP / 8>();
         W1_LAP(tw1);
         const f32x16 dP = mma_rows<DP, false, false, 8>(Vs, Gr, lo);
         asm volatile("" ::: "memory");
@@ -993,8 +998,8 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
         if (more) vtile(j0 + 32);
         W1_LAP(ti1);
         // K(t) (and, in the first tile, Q).  Behind them: V(t+1) if there is one, and in the first tile the O fragment
-        if (FIRST) { if (more) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-        else if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (FIRST) { if (more) w1_wait<2 * (DP / 8)>(); else w1_wait<DP / 8>(); }
+        else if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W1_LAP(tw2);
         const f32x16 S = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
@@ -1242,7 +1247,7 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
     auto tile = [&](auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool more = decltype(MORE_T)::value;
         const int i0 = t * 32;
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // Q(t); dO(t) may still be on its way
+        w1_wait<DP / 8>();           // Q(t); dO(t) may still be on its way
         const f32x16 S = mma_rows<DP, false, false, 8>(Qs, Kr, lo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // dO(t)
         const f32x16 dP = mma_rows<DP, false, false, 8>(Gs, Vr, lo);

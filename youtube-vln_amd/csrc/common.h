@@ -78,17 +78,25 @@ __device__ __forceinline__ float drop_scale1(const DropKey& k, uint64_t e, uint3
 
 // Cheap per-element keep decision for attention-probability dropout: one 32-bit hash per score, the same in every fragment layout (the forward
 // / dQ kernels hold 4 consecutive keys per lane, the dK/dV kernel 4 consecutive queries).  The element index enters through two odd multipliers
-// (lo * C1 is an add per element for the kernels: lo advances by compile-time steps), the site / step key by xor; one xor-shift and ONE more
-// multiply finish it -- the keep test compares the whole word against a threshold, i.e. reads the high bits, which a multiply fills from all
-// bits below.  Round 3: replaces the murmur3 finaliser (two multiplies, three xor-shifts, an add): per score element that was 2 of the ~25
-// issue slots of every attention kernel going to quarter-rate integer multiplies (v_mul_lo_u32) plus 5 plain ops, and a wave's VALU time is
-// not hidden under its matrix instructions.  Checked against the old hash on 6 x 4096 x 288 masks at p = 0.1: drop rate
-// 0.1002, neighbour correlations along keys / rows / diagonals / +32 keys all < 0.003 (the noise floor), per-row drop counts at the binomial
-// variance (ratio 1.00), top byte uniform (chi2 252 on 255 dof) -- the same figures as the finaliser.
+// (lo * C1 is an add per element for the kernels: lo advances by compile-time steps), the site / step key -- itself put through a full avalanche
+// once per wave, so that neighbouring sites and steps get unrelated keys -- by xor; then five FULL-RATE operations: a 24-bit multiply-add
+// (v_mad_u32_u24, fed by the low 24 bits, the high 24 added back), an xor-shift, a 24-bit multiply.  Round 3: replaces the murmur3 finaliser
+// applied per element (2 quarter-rate v_mul_lo_u32 + 6 plain ops = 56 issue cycles of the ~100 a score element cost each attention kernel;
+// now 20) -- a wave's VALU time is not hidden under its matrix instructions.  Quality, measured against the finaliser on
+// 4096 x 288 masks at p = 0.1 over 60 random key pairs: drop rate 0.1000 (0.0992-0.1006 per mask), correlations between neighbours along keys /
+// rows / diagonals / +32 keys <= 0.003, correlation between the masks of two keys 0.0009 rms / 0.0033 max -- all at the sampling-noise floor
+// (0.0009), as for the finaliser.  (A version with ONE 32-bit multiply also passes the single-mask tests but leaves 0.0025 rms / 0.013 max
+// between masks of different keys: rejected.)
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ uint32_t attn_drop_hash(uint32_t lo, uint32_t hi, const DropKey& k) {
-    uint32_t x = (lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u) ^ (k.k0 ^ k.k1 ^ k.s0);
-    x ^= x >> 15;
-    return x * 0x2C1B3C6Du;
+    const uint32_t kx = fmix32(k.k0 ^ fmix32((k.s0 + 0x9E3779B9u) ^ k.k1));      // (wave-invariant: computed once)
+    uint32_t x = (lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u) ^ kx;
+    x = __umul24(x, 0x6B43A9u) + (x >> 8);
+    x ^= x >> 12;
+    return __umul24(x, 0xB5297Au);
 }
 
 // ---- wave / block reductions ------------------------------------------------------------------------------------
