@@ -94,9 +94,9 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 __device__ __forceinline__ uint32_t attn_drop_hash(uint32_t lo, uint32_t hi, const DropKey& k) {
     const uint32_t kx = fmix32(k.k0 ^ fmix32((k.s0 + 0x9E3779B9u) ^ k.k1));      // (wave-invariant: computed once)
     uint32_t x = (lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u) ^ kx;
-    x = __umul24(x, 0x6B43A9u) + (x >> 8);
+    x = (uint32_t)__umul24(x, 0x6B43A9u) + (x >> 8);
     x ^= x >> 12;
-    return __umul24(x, 0xB5297Au);
+    return (uint32_t)__umul24(x, 0xB5297Au);
 }
 
 // ---- wave / block reductions ------------------------------------------------------------------------------------
