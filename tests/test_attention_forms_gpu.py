@@ -3,7 +3,7 @@
 The one-wave-per-SIMD kernels (attention.hip: attn_fwd_w1_body, attn_bwd_dq_w1_body, attn_bwd_dkv_w1_body) replace the two-wave / wave-pair
 kernels for launches that meet their conditions (unpadded d = 128 heads, fp32 operands; dK/dV: at least two rounds of wave slots).  The small
 shapes of test_kernels_gpu.py do not all meet them, and the choice is read once per process, so this test drives tools/attn_form_check.py:
-each form in its own process, same seeded inputs, fourteen shapes (d = 128 and d = 64; ragged tiles, fully masked rows, dropout on and off, single
+each form in its own process, same seeded inputs, seventeen shapes (d = 128 and d = 64; sequences up to the 512 the one-wave kernels take; ragged tiles, fully masked rows, dropout on and off, single
 tile, padded head dimensions, 576 keys), outputs compared tensor by tensor."""
 import os
 import subprocess

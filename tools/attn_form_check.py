@@ -9,7 +9,8 @@ SHAPES = [  # N, heads, d, Tq, Tk, p, masked
     (3, 8, 128, 288, 288, 0.1, True), (3, 8, 128, 288, 80, 0.1, True), (3, 8, 128, 80, 288, 0.1, True), (2, 2, 128, 37, 101, 0.0, True),
     (2, 3, 96, 65, 33, 0.1, False), (1, 1, 128, 1, 1, 0.0, False), (2, 2, 128, 32, 32, 0.1, True), (2, 2, 128, 33, 64, 0.1, True),
     (1, 2, 128, 576, 576, 0.1, True), (2, 4, 68, 100, 31, 0.2, True),
-    (3, 12, 64, 80, 80, 0.1, True), (2, 4, 64, 100, 37, 0.1, True), (1, 2, 64, 32, 32, 0.0, False), (2, 3, 64, 33, 288, 0.1, True)]
+    (3, 12, 64, 80, 80, 0.1, True), (2, 4, 64, 100, 37, 0.1, True), (1, 2, 64, 32, 32, 0.0, False), (2, 3, 64, 33, 288, 0.1, True),
+    (1, 2, 128, 500, 512, 0.1, True), (1, 3, 64, 512, 490, 0.1, True), (1, 1, 128, 64, 481, 0.0, True)]          # the longest rows the one-wave kernels take
 
 def child(path):
     sys.path.insert(0, os.path.join(ROOT, "youtube-vln_amd"))
