@@ -916,13 +916,6 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
 template <int DP, bool DROP>
 __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP, NJ = DP / 32;
-#ifdef YTVLN_W1_TIMING
-    const uint64_t c_entry = __builtin_amdgcn_s_memtime();
-    uint64_t tw1 = 0, tp1 = 0, ti1 = 0, tw2 = 0, tp2 = 0, tv = 0, tp3 = 0, ti3 = 0, c0, c1;
-#define W1_LAP(acc) do { c1 = __builtin_amdgcn_s_memtime(); acc += c1 - c0; c0 = c1; } while (0)
-#else
-#define W1_LAP(acc) do {} while (0)
-#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ Ks = smem;
     float* __restrict__ Vs = smem + TS;
@@ -978,10 +971,6 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
     uint32_t thr = 0; float ik = 1.f;
     const uint32_t dlo = (uint32_t)sidx;
     if (DROP) { thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
-#ifdef YTVLN_W1_TIMING
-    c0 = __builtin_amdgcn_s_memtime();
-    const uint64_t cstart = c0;
-#endif
     // one key tile; FIRST: tile 0, with the Q fragment (DP/8 loads) and, when this kernel also produces delta, the O fragment (DP/8 more) still in
     // the queue behind K(0)
     auto tile = [&](auto FIRST_T, const int t) __attribute__((always_inline)) {
@@ -991,22 +980,14 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
         // V(t).  Behind it in the queue: K(t) (DP/8 pieces); in the first tile K(0) and dO (needed now as well), then Q and O
         if (FIRST) w1_wait<2 * (DP / 8)>();
         else w1_wait<DP / 8>();
-        W1_LAP(tw1);
         const f32x16 dP = mma_rows<DP, false, false, 8>(Vs, Gr, lo);
         asm volatile("" ::: "memory");
-        W1_LAP(tp1);
         if (more) vtile(j0 + 32);
-        W1_LAP(ti1);
         // K(t) (and, in the first tile, Q).  Behind them: V(t+1) if there is one, and in the first tile the O fragment
         if (FIRST) { if (more) w1_wait<2 * (DP / 8)>(); else w1_wait<DP / 8>(); }
         else if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W1_LAP(tw2);
         const f32x16 S = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
-#ifdef YTVLN_W1_TIMING
-        { float sink = S[0]; asm volatile("" : "+v"(sink)); }
-#endif
-        W1_LAP(tp2);
         if constexpr (FIRST) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -1034,35 +1015,13 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
                 dS[r] = p * (dp - dl);
             }
         }
-#ifdef YTVLN_W1_TIMING
-        { float sink = dS[15]; asm volatile("" : "+v"(sink)); }
-#endif
-        W1_LAP(tv);
         mma_regs_rows<DP, false, false, 8>(dQ, dS, Ks, lo);
         asm volatile("" ::: "memory");
-        W1_LAP(tp3);
         if (more) ktile(j0 + 32);
-        W1_LAP(ti3);
     };
     tile(std::true_type{}, 0);
     for (int t = 1; t < ntiles; ++t) tile(std::false_type{}, t);
-#ifdef YTVLN_W1_TIMING
-    const uint64_t c_loop_end = __builtin_amdgcn_s_memtime();
-#endif
     store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
-#ifdef YTVLN_W1_TIMING
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint64_t c_end = __builtin_amdgcn_s_memtime();
-        if ((blockIdx.x == gridDim.x / 2 + 3 || blockIdx.x == 5) && lane == 0)
-            printf("w1 dq timing (cycles, wave %d, %d tiles): prologue %llu | loop %llu: wait V %llu  dP %llu  issue V %llu  wait K %llu  S %llu  dS valu %llu  dQ %llu  issue K %llu | "
-                   "store %llu | total %llu\n", (int)blockIdx.x, ntiles, (unsigned long long)(cstart - c_entry), (unsigned long long)(c_loop_end - cstart),
-                   (unsigned long long)tw1, (unsigned long long)tp1, (unsigned long long)ti1, (unsigned long long)tw2, (unsigned long long)tp2,
-                   (unsigned long long)tv, (unsigned long long)tp3, (unsigned long long)ti3, (unsigned long long)(c_end - c_loop_end),
-                   (unsigned long long)(c_end - c_entry));
-    }
-#endif
-#undef W1_LAP
 }
 
 // dK / dV.  A PAIR of waves owns 32 keys: wave "S" (role 0) keeps the K fragment and the dV accumulators, wave "D" (role 1) the V
