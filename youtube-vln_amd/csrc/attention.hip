@@ -728,6 +728,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
 template <int N>
 __device__ __forceinline__ void w1_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifndef W1_PIPE
+#define W1_PIPE 8          // LDS fragment reads in flight ahead of the matrix instructions of the one-wave kernels (mma_rows / mma_regs_rows); measured: 4 the same within 1 %, 16 slower (backward 703 -> 738 us: registers)
+#endif
 // One LDS-DMA stream of the one-wave kernels: 32-row x DP-column tiles of a row-major matrix into a private LDS buffer, DP/8 pieces of 1 KiB
 // (256/DP rows each; the Tile<DP> layout: granule g of row r at position g ^ (r & 7)).  Per piece of a FULL tile: one add and one 64-bit add on
 // the vector unit, one scalar move for M0 (the per-lane offsets row * ld + granule column are lane constants, the LDS side is address-space-3
@@ -833,7 +836,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // K(t); V(t) (DP/8 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else w1_wait<DP / 8>();
-        const f32x16 S = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, false, false, W1_PIPE>(Ks, Qr, lo);
         asm volatile("" ::: "memory");
         if (more) ks.issue(j0 + 32);
         if constexpr (FIRST) {
@@ -879,7 +882,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // V(t); K(t+1), if there is one, may still be on its way
         if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mma_regs_rows<DP, false, false, 8>(O, P, Vs, lo);
+        mma_regs_rows<DP, false, false, W1_PIPE>(O, P, Vs, lo);
         asm volatile("" ::: "memory");
         if (more) vs.issue(j0 + 32);
     };
@@ -980,14 +983,14 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
         // V(t).  Behind it in the queue: K(t) (DP/8 pieces); in the first tile K(0) and dO (needed now as well), then Q and O
         if (FIRST) w1_wait<2 * (DP / 8)>();
         else w1_wait<DP / 8>();
-        const f32x16 dP = mma_rows<DP, false, false, 8>(Vs, Gr, lo);
+        const f32x16 dP = mma_rows<DP, false, false, W1_PIPE>(Vs, Gr, lo);
         asm volatile("" ::: "memory");
         if (more) vtile(j0 + 32);
         // K(t) (and, in the first tile, Q).  Behind them: V(t+1) if there is one, and in the first tile the O fragment
         if (FIRST) { if (more) w1_wait<2 * (DP / 8)>(); else w1_wait<DP / 8>(); }
         else if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const f32x16 S = mma_rows<DP, false, false, 8>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, false, false, W1_PIPE>(Ks, Qr, lo);
         if constexpr (FIRST) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -1015,7 +1018,7 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
                 dS[r] = p * (dp - dl);
             }
         }
-        mma_regs_rows<DP, false, false, 8>(dQ, dS, Ks, lo);
+        mma_regs_rows<DP, false, false, W1_PIPE>(dQ, dS, Ks, lo);
         asm volatile("" ::: "memory");
         if (more) ktile(j0 + 32);
     };
@@ -1207,9 +1210,9 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
         constexpr bool more = decltype(MORE_T)::value;
         const int i0 = t * 32;
         w1_wait<DP / 8>();           // Q(t); dO(t) may still be on its way
-        const f32x16 S = mma_rows<DP, false, false, 8>(Qs, Kr, lo);
+        const f32x16 S = mma_rows<DP, false, false, W1_PIPE>(Qs, Kr, lo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // dO(t)
-        const f32x16 dP = mma_rows<DP, false, false, 8>(Gs, Vr, lo);
+        const f32x16 dP = mma_rows<DP, false, false, W1_PIPE>(Gs, Vr, lo);
         float Pk[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1230,10 +1233,10 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
                 dS[r] = p * (dp - dsv[u]);
             }
         }
-        mma_regs_rows<DP, false, false, 8>(accK, dS, Qs, lo);          // dK += dS^T . Q
+        mma_regs_rows<DP, false, false, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
         asm volatile("" ::: "memory");
         if (more) qtile(i0 + 32);
-        mma_regs_rows<DP, false, false, 8>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
+        mma_regs_rows<DP, false, false, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
         asm volatile("" ::: "memory");
         if (more) gtile(i0 + 32);
     };
