@@ -634,11 +634,16 @@ def main():
         ms, flop, n, shapes = timer.summary()
         ach = flop / (ms * 1e-3) / 1e12
         traffic, traffic_note = None, None
-        try:     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (cannot be collected in-process)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc_summary.json")))
+        try:     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (cannot be collected in-process): the newest committed summary
+            import glob
+            import re
+            cands = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_summary.json"))
+                            if re.fullmatch(r"round\d+_pmc_summary\.json", os.path.basename(f))),
+                           key=lambda f: int(re.search(r"round(\d+)_", os.path.basename(f)).group(1)))
+            pmc = json.load(open(cands[-1]))
             traffic = pmc["kernels"]["gemm_dma"]["hbm_side_bytes_per_launch"]
-            traffic_note = "profiles/round2_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
-        except (OSError, KeyError, ValueError):
+            traffic_note = f"profiles/{os.path.basename(cands[-1])}: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
+        except (OSError, KeyError, ValueError, IndexError, AttributeError):
             pass
         # fp32x3: six bf16 matrix instructions per algorithmic product -> the ceiling for algorithmic FLOPs is the bf16 peak / 6
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32x3": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}[a.precision]
@@ -685,38 +690,6 @@ def main():
                              "work_per_step": round(abytes / nsteps_prof / 1e9, 3), "work_unit": "GB algorithmic (28 B per parameter that has a gradient)",
                              "achieved": round(abytes / (fms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(abytes / (fms * 1e-3) / 1e9 / 8000.0, 4)}
         out["roofline"]["families"] = fams
-        if a.precision == "fp32" and rank == 0:
-            # What the fraction of the NOMINAL peak is made of: the dominant GEMM shape once more on random operands with the C ABI's clock
-            # probe -- shader cycles of the main loop against the cycles the matrix pipe needs, and the shader clock the chip actually ran
-            # at (it depends on the operand data: ~2.0-2.25 GHz on random operands, 2.3-2.4 GHz on constant ones)
-            try:
-                import ctypes
-                from ytvln import _lib as yt_lib
-                (Mh, Nh, Kh, tah, tbh), _ = max(shapes.items(), key=lambda kv: kv[1][1])
-                Ah = torch.randn((Kh, Mh) if tah else (Mh, Kh), device=dev)
-                Bh = torch.randn((Nh, Kh) if tbh else (Kh, Nh), device=dev)
-                Ch = torch.empty(Mh, Nh, device=dev)
-                for _ in range(5):
-                    yt_ops._gemm(Ah, Mh if tah else Kh, tah, Bh, Kh if tbh else Nh, tbh, Ch, Nh, Mh, Nh, Kh)
-                yt_lib.call("ytvln_gemm_clock_probe", 1)
-                res = (ctypes.c_double * 8)()
-                acc = []
-                for _ in range(3):
-                    yt_ops._gemm(Ah, Mh if tah else Kh, tah, Bh, Kh if tbh else Nh, tbh, Ch, Nh, Mh, Nh, Kh)
-                    yt_lib.call("ytvln_gemm_clock_result", res)
-                    acc.append(list(res))
-                yt_lib.call("ytvln_gemm_clock_probe", 0)
-                r = acc[-1]
-                if r[2] > 0:
-                    out["roofline"]["clock"] = {"shape": [Mh, Nh, Kh, tah, tbh], "kernel_us": round(r[0], 1), "main_loop_us": round(r[1], 1),
-                                                "main_loop_cycle_frac": round(r[3] / r[2], 4), "shader_ghz_under_load": round(r[4], 3),
-                                                "nominal_ghz": 2.4, "peak_at_measured_clock": round(PEAK_F32_MFMA_TFLOPS * r[4] / 2.4, 1),
-                                                "prologue_us": round(r[6], 1), "epilogue_us": round(r[7], 1), "operands": "random normal",
-                                                "note": "frac of the nominal peak = cycle fraction x (clock under load / 2.4 GHz) x launch-level overheads; the clock under "
-                                                        "load is set by the chip's power management and depends on the operand data"}
-                del Ah, Bh, Ch
-            except Exception as e:
-                out["roofline"]["clock"] = {"error": f"{type(e).__name__}: {e}"}
         if a.kernel_table and rank == 0:
             rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
             print(f"{'M':>7} {'N':>6} {'K':>6} tA tB {'calls':>6} {'ms':>9} {'TF/s':>7}", file=sys.stderr)

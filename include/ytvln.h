@@ -32,6 +32,15 @@ extern "C" {
 int ytvln_version(void);
 const char* ytvln_last_error(void);
 
+/* Run-time options: the complete set of switches the library reads (kernel-form selection for tests and experiments; nothing a
+ * production run has to touch).  An option starts from the environment variable YTVLN_<NAME> (read at first use) and can be set at any
+ * time; INTEGRATION.md section 4 lists every name, default and meaning.  Names may be given with or without the "YTVLN_" prefix.
+ *   ytvln_option_count / ytvln_option_name enumerate the table (index 0 .. count-1); set / get return 0, or -1 for an unknown name. */
+int ytvln_option_count(void);
+const char* ytvln_option_name(int index);
+int ytvln_set_option(const char* name, int value);
+int ytvln_get_option(const char* name, int* value);
+
 /* activation / epilogue selectors for ytvln_gemm_f32 */
 enum {
     YTVLN_EPI_NONE = 0,       /* C = A.B (+bias)                                                             */
@@ -56,7 +65,7 @@ enum {
 #define YTVLN_GEMM_A_ZERO_PADDED 1
 /* opt-in: every fp32 operand value is split exactly into three bf16 terms in registers and each product is accumulated in fp32
  * from the six largest cross terms on the bf16 matrix instruction (error per product ~ one fp32 rounding; LDS-DMA path only,
- * ignored by the generic kernel and by stream-K launches).  Finite inputs only: an infinite operand value yields NaN (inf - inf in the
+ * ignored by the generic kernel).  Finite inputs only: an infinite operand value yields NaN (inf - inf in the
  * split) where the native instruction would propagate the infinity. */
 #define YTVLN_GEMM_SPLIT_BF16X3 2
 int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue);
@@ -66,14 +75,6 @@ int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, 
 /* the same for a launch carrying YTVLN_GEMM_SPLIT_BF16X3 (its planner has its own per-tile costs; 256x256 tiles also for transA = 1 and
  * with split-K) */
 int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits);
-/* Measurement aid: with the probe enabled every following ytvln_gemm_f32 launch that takes the LDS-DMA main
- * loop records per-workgroup clocks (s_memrealtime / s_memtime around its main loop), SYNCHRONISES the device and leaves a summary for
- * ytvln_gemm_clock_result: out8 = {kernel us, mean main-loop us, mean main-loop shader cycles, matrix-pipe cycles the loop needs at
- * 64 FLOP/clk/SIMD, shader clock under load in GHz (cycles / us), workgroups, mean prologue us, mean epilogue us}.  It exists because the
- * chip's clock under fp32 matrix load depends on the operand DATA (random operands ~2.0-2.25 GHz, constant operands 2.3-2.4 GHz), so a
- * fraction of the nominal 2.4 GHz peak mixes two things a kernel author controls only one of.  Not for production paths. */
-int ytvln_gemm_clock_probe(int enable);
-int ytvln_gemm_clock_result(double* out8);
 int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                    int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                    float beta, float* workspace, int64_t workspace_elems, int flags, void* stream);

@@ -1,5 +1,5 @@
 """Per-shape GEMM rates at the cfg-2 shapes (HIP events, 20 launches each).  Planner knobs are process-wide environment variables
-(YTVLN_GEMM_BIG_TA, YTVLN_GEMM_TILE, YTVLN_GEMM_SPLITS ...): run once per setting.  SHAPES=wgrad|dx|fwd|all."""
+(YTVLN_GEMM_TILE, YTVLN_GEMM_SPLITS: the options of include/ytvln.h, read from the environment at first use): run once per setting.  SHAPES=wgrad|dx|fwd|all."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd"))
 import torch

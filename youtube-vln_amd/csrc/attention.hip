@@ -168,16 +168,12 @@ __device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, floa
 #define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // acc (32x32)[tile row][lane's own row] = Xs-tile (A: rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T (B: registers)
-template <int DP, bool BF = false, bool NOLDS = false, int PIPE = 0>
+template <int DP, bool BF = false, int PIPE = 0>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (NOLDS) {          // timing probe only (YTVLN_ATTN_PROBES builds): the matrix instructions without their LDS operand reads
-#pragma unroll
-        for (int s4 = 0; s4 < DP / 2; ++s4) acc = MFMA(R[s4 ^ 1], R[s4], acc);
-        return acc;
-    } else if constexpr (BF) {
+    if constexpr (BF) {
 #pragma unroll
         for (int s8 = 0; s8 < DP / 2; s8 += 8) {       // this half-wave's contraction values s8 .. s8+7 (two 16-byte granules of the row)
             const int g0 = s8 >> 2, g1 = g0 + 1;
@@ -226,15 +222,10 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 
 // acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
 //                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
-template <int DP, bool BF = false, bool NOLDS = false, int PIPE = 0>
+template <int DP, bool BF = false, int PIPE = 0>
 __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo) {
     constexpr int NJ = DP / 32;
-    if constexpr (NOLDS) {          // timing probe only
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r], P[r ^ 1], acc[j]);
-    } else if constexpr (BF) {
+    if constexpr (BF) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {          // tile rows krow(8s .. 8s+7, half): the order the P registers hold them
             float x[8][NJ];
@@ -325,12 +316,10 @@ __device__ __forceinline__ void store_rows(const f32x16 (&acc)[DP / 32], float* 
 template <int DP, bool DROP>
 __device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const int bx, const int h, const int n);      // below
 
-// PROBE (timing experiments, YTVLN_ATTN_PROBES builds only; results are wrong by construction): 1 no waits / barriers, 2 no DMA,
-// 4 no softmax arithmetic, 8 no K.Q^T matrix instructions, 16 no P.V matrix instructions, 32 matrix instructions without LDS reads.
-template <int DP, bool DROP, bool BF, int PROBE = 0>
+template <int DP, bool DROP, bool BF>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP, NJ = DP / 32;
-    if constexpr (DP == 128 && !BF && PROBE == 0) {
+    if constexpr (DP == 128 && !BF) {
         // a two-wave workgroup holding a single query tile shares it between its waves (d-split form above); workgroup-uniform
         if (a.dsplit && blockDim.x == 128 && (bx * 2 + 1) * 32 >= a.Tq) {
             attn_fwd_dsplit_body<DP, DROP>(a, bx, h, n);
@@ -377,21 +366,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
 
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32;
-        if constexpr (!(PROBE & 1)) TILE_WAIT_AND_SYNC();
-        if constexpr (!(PROBE & 2)) Tile<DP>::issue(Vs, vb, ldv, j0, a.Tk, a.d, wave, nw, lane);
+        TILE_WAIT_AND_SYNC();
+        Tile<DP>::issue(Vs, vb, ldv, j0, a.Tk, a.d, wave, nw, lane);
         if (active) {
-            f32x16 S;
-            if constexpr (PROBE & 8) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[r] = Qr[r] + (float)t;
-            } else {
-                S = mma_rows<DP, BF, (PROBE & 32) != 0, 8>(Ks, Qr, lo);
-            }
-            if constexpr (PROBE & 4) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) P[r] = S[r];
-                l += P[0];
-            } else {
+            const f32x16 S = mma_rows<DP, BF, 8>(Ks, Qr, lo);
             float mt = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -430,17 +408,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
                     P[r] = bits >= thr ? P[r] * ik : 0.f;
                 }
             }
-            }
         }
-        if constexpr (!(PROBE & 1)) TILE_WAIT_AND_SYNC();
-        if constexpr (!(PROBE & 2)) {
-            if (t + 1 < ntiles) Tile<DP>::issue(Ks, kb, ldk, j0 + 32, a.Tk, a.d, wave, nw, lane);
-        }
-        if constexpr (!(PROBE & 16)) {
-            if (active) mma_regs_rows<DP, BF, (PROBE & 32) != 0, 8>(O, P, Vs, lo);
-        } else {
-            if (active) O[0][t & 15] += P[t & 15];
-        }
+        TILE_WAIT_AND_SYNC();
+        if (t + 1 < ntiles) Tile<DP>::issue(Ks, kb, ldk, j0 + 32, a.Tk, a.d, wave, nw, lane);
+        if (active) mma_regs_rows<DP, BF, 8>(O, P, Vs, lo);
     }
     if (active) {
         const float inv = 1.0f / l;
@@ -606,33 +577,6 @@ __device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const in
     if (w == 0 && qvalid && half == 0) a.lse_out[((int64_t)n * a.heads + h) * a.Tq + qi] = m + logf(l);
 }
 
-// delta[n,h,q] = sum_c dctx[n,q,h*d+c] * ctx[n,q,h*d+c]
-// LG lanes (a power of two >= d/4) share one (row, head) segment: every lane moves one 16-byte piece of ctx and dctx, so a wave
-// sweeps 1 KiB of each row contiguously; the segment sum is a log2(LG)-step shuffle reduction (fixed order -> deterministic).
-template <int LG>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ ctx, const float* __restrict__ dctx, int64_t ldo,
-                                                         float* __restrict__ delta, int N, int heads, int Tq, int d) {
-    const int64_t total = (int64_t)N * Tq * heads;
-    const int sub = threadIdx.x % LG;
-    const int d4 = d >> 2;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LG; i < total; i += (int64_t)gridDim.x * (256 / LG)) {
-        const int h = (int)(i % heads);
-        const int64_t row = i / heads;   // n*Tq + q
-        float acc = 0.f;
-        if (sub < d4) {
-            const float4 x = reinterpret_cast<const float4*>(ctx + row * ldo + h * d)[sub];
-            const float4 y = reinterpret_cast<const float4*>(dctx + row * ldo + h * d)[sub];
-            acc = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-        }
-#pragma unroll
-        for (int o = LG / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (sub == 0) {
-            const int64_t nn = row / Tq, q = row % Tq;
-            delta[(nn * heads + h) * Tq + q] = acc;
-        }
-    }
-}
-
 // dQ.  LDS as in the forward.  Per key tile t:
 //     wait+barrier (V(t) landed, everyone finished dS.K(t-1)) -> DMA K(t)   | dP^T = V(t).dO^T
 //     wait+barrier (K(t) landed, everyone finished V(t).dO^T) -> DMA V(t+1) | S^T = K(t).Q^T, dS, dQ += dS.K(t)
@@ -664,9 +608,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     load_rowfrag<DP, BF>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
     float dl;
-    if (a.delta_out) {
-        // delta = sum_c dO[q][c] * O[q][c] for this lane's query: each half-wave holds half of the head dimension (same association as
-        // attn_delta_kernel is not required -- delta is consumed through the same value by both backward kernels)
+    {
+        // delta = sum_c dO[q][c] * O[q][c] for this lane's query (each half-wave holds half of the head dimension); written for the dK/dV
+        // kernel, which follows on the stream
         float Cr[DP / 2];          // the O fragment: dead before the accumulators come alive; all three fragments' loads fly together
         load_rowfrag<DP, BF>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
         load_rowfrag<DP, BF>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
@@ -675,9 +619,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
         for (int s4 = 0; s4 < DP / 2; s4 += 4) acc += (Cr[s4] * Gr[s4] + Cr[s4 + 1] * Gr[s4 + 1]) + (Cr[s4 + 2] * Gr[s4 + 2] + Cr[s4 + 3] * Gr[s4 + 3]);
         dl = acc + __shfl_xor(acc, 32, 64);
         if (active && qvalid && half == 0) a.delta_out[sidx] = dl;
-    } else {
-        dl = qvalid ? a.delta[sidx] : 0.f;
-        load_rowfrag<DP, BF>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     }
     const float lse = qvalid ? a.lse[sidx] : INFINITY;          // a query past the end: p = exp(-inf) = 0
     for (int j = tid; j < ntiles * 32; j += nthr) Mrow[j] = j < a.Tk ? (a.mask ? a.mask[krow_base + j] : 0.f) : -INFINITY;
@@ -698,11 +639,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
         const int j0 = t * 32;
         TILE_WAIT_AND_SYNC();
         Tile<DP>::issue(Ks, kb, ldk, j0, a.Tk, a.d, wave, nw, lane);
-        if (active) dP = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Vs, Gr, lo);
+        if (active) dP = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Vs, Gr, lo);
         TILE_WAIT_AND_SYNC();
         if (t + 1 < ntiles) Tile<DP>::issue(Vs, vb, ldv, j0 + 32, a.Tk, a.d, wave, nw, lane);
         if (active) {
-            const f32x16 S = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Ks, Qr, lo);
+            const f32x16 S = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Ks, Qr, lo);
             float dS[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -717,7 +658,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
                     dS[r] = p * (dp - dl);
                 }
             }
-            mma_regs_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(dQ, dS, Ks, lo);
+            mma_regs_rows<DP, BF, YT_ATTN_BWD_PIPE>(dQ, dS, Ks, lo);
         }
     }
     if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
@@ -808,8 +749,10 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
     }
     ks.issue(0);
     vs.issue(0);
+    __builtin_amdgcn_sched_barrier(0);          // (the counted waits below assume this issue order: pin it -- ADVICE r3)
     float Qr[DP / 2];          // (a query past the end repeats the last one: its row of O and its lse are not stored)
     load_rowfrag_raw<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, half);
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x16 O[NJ];
 #pragma unroll
@@ -836,7 +779,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // K(t); V(t) (DP/8 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else w1_wait<DP / 8>();
-        const f32x16 S = mma_rows<DP, false, false, W1_PIPE>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, false, W1_PIPE>(Ks, Qr, lo);
         asm volatile("" ::: "memory");
         if (more) ks.issue(j0 + 32);
         if constexpr (FIRST) {
@@ -882,7 +825,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // V(t); K(t+1), if there is one, may still be on its way
         if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mma_regs_rows<DP, false, false, W1_PIPE>(O, P, Vs, lo);
+        mma_regs_rows<DP, false, W1_PIPE>(O, P, Vs, lo);
         asm volatile("" ::: "memory");
         if (more) vs.issue(j0 + 32);
     };
@@ -958,13 +901,21 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
     }
     const float lse = qvalid ? a.lse[sidx] : INFINITY;
     float dl;                                // (this kernel always produces delta itself: launch condition)
+    // The counted vmcnt waits of the first tile assume EXACTLY this issue order -- V(0), K(0), dO, Q, O -- so it is pinned: nothing but hipcc's
+    // scheduling of the day would otherwise keep a plain global load from moving across an LDS-DMA builtin.
+    __builtin_amdgcn_sched_barrier(0);
     vtile(0);
+    __builtin_amdgcn_sched_barrier(0);
     float Qr[DP / 2], Gr[DP / 2], Cr[DP / 2];
     // (d == DP: the launch takes this kernel only for unpadded heads -- load_rowfrag_raw; two code paths would meet in register copies, i.e. waits)
     ktile(0);          // (both DMA tiles ahead of the register loads: an LDS read next to an LDS-DMA still in flight makes hipcc wait for everything)
+    __builtin_amdgcn_sched_barrier(0);
     load_rowfrag_raw<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, half);
+    __builtin_amdgcn_sched_barrier(0);
     load_rowfrag_raw<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, half);
+    __builtin_amdgcn_sched_barrier(0);
     load_rowfrag_raw<DP>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, half);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 dQ[NJ];
 #pragma unroll
     for (int c = 0; c < NJ; ++c)
@@ -983,14 +934,14 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
         // V(t).  Behind it in the queue: K(t) (DP/8 pieces); in the first tile K(0) and dO (needed now as well), then Q and O
         if (FIRST) w1_wait<2 * (DP / 8)>();
         else w1_wait<DP / 8>();
-        const f32x16 dP = mma_rows<DP, false, false, W1_PIPE>(Vs, Gr, lo);
+        const f32x16 dP = mma_rows<DP, false, W1_PIPE>(Vs, Gr, lo);
         asm volatile("" ::: "memory");
         if (more) vtile(j0 + 32);
         // K(t) (and, in the first tile, Q).  Behind them: V(t+1) if there is one, and in the first tile the O fragment
         if (FIRST) { if (more) w1_wait<2 * (DP / 8)>(); else w1_wait<DP / 8>(); }
         else if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const f32x16 S = mma_rows<DP, false, false, W1_PIPE>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, false, W1_PIPE>(Ks, Qr, lo);
         if constexpr (FIRST) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -1018,7 +969,7 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
                 dS[r] = p * (dp - dl);
             }
         }
-        mma_regs_rows<DP, false, false, W1_PIPE>(dQ, dS, Ks, lo);
+        mma_regs_rows<DP, false, W1_PIPE>(dQ, dS, Ks, lo);
         asm volatile("" ::: "memory");
         if (more) ktile(j0 + 32);
     };
@@ -1095,7 +1046,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
         if (active) {
             if (role == 0) {
                 // S[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
-                const f32x16 S = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Qs, Fr, lo);
+                const f32x16 S = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Qs, Fr, lo);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
@@ -1104,7 +1055,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                     *reinterpret_cast<float4*>(Xp + (g * 64 + lane) * 4) = make_float4(W[4 * g], W[4 * g + 1], W[4 * g + 2], W[4 * g + 3]);
                 }
             } else {
-                const f32x16 dP = mma_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(Gs, Fr, lo);
+                const f32x16 dP = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Gs, Fr, lo);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) W[r] = dP[r];
             }
@@ -1117,7 +1068,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                     for (int r = 0; r < 16; ++r)
                         W[r] = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + krow(r, half)), key) >= thr ? W[r] * ik : 0.f;
                 }
-                mma_regs_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(acc, W, Gs, lo);          // dV += P~^T . dO
+                mma_regs_rows<DP, BF, YT_ATTN_BWD_PIPE>(acc, W, Gs, lo);          // dV += P~^T . dO
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1132,7 +1083,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                         W[r] = pvv[u] * (dp - dsv[u]);
                     }
                 }
-                mma_regs_rows<DP, BF, false, YT_ATTN_BWD_PIPE>(acc, W, Qs, lo);          // dK += dS^T . Q
+                mma_regs_rows<DP, BF, YT_ATTN_BWD_PIPE>(acc, W, Qs, lo);          // dK += dS^T . Q
             }
         }
         if (STAGES == 1 && t + 1 < nqt) {
@@ -1210,9 +1161,9 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
         constexpr bool more = decltype(MORE_T)::value;
         const int i0 = t * 32;
         w1_wait<DP / 8>();           // Q(t); dO(t) may still be on its way
-        const f32x16 S = mma_rows<DP, false, false, W1_PIPE>(Qs, Kr, lo);
+        const f32x16 S = mma_rows<DP, false, W1_PIPE>(Qs, Kr, lo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // dO(t)
-        const f32x16 dP = mma_rows<DP, false, false, W1_PIPE>(Gs, Vr, lo);
+        const f32x16 dP = mma_rows<DP, false, W1_PIPE>(Gs, Vr, lo);
         float Pk[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1233,10 +1184,10 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
                 dS[r] = p * (dp - dsv[u]);
             }
         }
-        mma_regs_rows<DP, false, false, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
+        mma_regs_rows<DP, false, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
         asm volatile("" ::: "memory");
         if (more) qtile(i0 + 32);
-        mma_regs_rows<DP, false, false, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
+        mma_regs_rows<DP, false, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
         asm volatile("" ::: "memory");
         if (more) gtile(i0 + 32);
     };
@@ -1284,10 +1235,6 @@ struct AttnLaunch { AttnArgs p[2]; int nb0, gx0, gx1; };
 
 template <int DP, bool DROP, bool BF>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<DP, DROP, BF>(a, bx, h, n))); }
-#ifdef YTVLN_ATTN_PROBES
-template <int PROBE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_probe_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<128, true, false, PROBE>(a, bx, h, n))); }
-#endif
 template <int DP, bool DROP>
 __global__ __launch_bounds__(64) void attn_fwd_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_w1_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP>
@@ -1300,17 +1247,10 @@ template <int DP, bool DROP, bool BF, int STAGES>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_body<DP, DROP, BF, STAGES>(a, bx, h, n))); }
 #undef YT_ATTN_DECODE
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 // Waves per workgroup of the forward / dQ kernels (32 queries each).  d > 64 (256-VGPR kernels, two waves per SIMD, 33 KB of LDS): two-wave
 // workgroups -- four of them fill a CU's eight wave slots, and a sequence of 9 query tiles costs one idle wave in five workgroups.  Smaller
 // heads run three waves per SIMD, so the shape with the fewest idle waves wins (ties: more waves share a staged tile).
 static int pick_waves(int T, int d) {
-    static const int force = env_int("YTVLN_ATTN_WAVES", 0);      // experiment knob
-    if (force >= 1 && force <= 4) return force;
     const int tiles = (int)cdiv(T, 32);
     if (d > 64) return tiles == 1 ? 1 : 2;
     int best = 1, best_idle = 1 << 30;
@@ -1322,16 +1262,12 @@ static int pick_waves(int T, int d) {
 }
 // Pairs of waves per workgroup of the dK/dV kernel (32 keys per pair) and the number of Q/dO tile stages.
 static int pick_pairs(int T, int d, int bf16) {
-    static const int force = env_int("YTVLN_ATTN_PAIRS", 0);
-    if (force >= 1 && force <= 2) return force;
     const int tiles = (int)cdiv(T, 32);
     if (tiles == 1) return 1;
     if (bf16) return 2;          // (the one-stage bf16 instantiation at d = 128 spills 200+ registers: two pairs, two stages)
     return d > 64 ? 1 : 2;
 }
 static int pick_stages(int d, int npairs, int bf16) {
-    static const int force = env_int("YTVLN_ATTN_DKV_STAGES", 0);
-    if (force >= 1 && force <= 2) return force;
     if (bf16) return 2;
     return (d > 64 && npairs == 1) ? 1 : 2;
 }
@@ -1395,23 +1331,6 @@ static size_t lds_dkv(int dp, int stages, int npairs, int Tq) {
 
 using namespace ytvln;
 
-static void launch_delta(const float* ctx, const float* dctx, int64_t ldo, float* delta, int N, int heads, int Tq, int d, hipStream_t s) {
-    const int64_t total = (int64_t)N * Tq * heads;
-    const int d4 = d / 4;
-    const int lg = d4 <= 1 ? 1 : d4 <= 2 ? 2 : d4 <= 4 ? 4 : d4 <= 8 ? 8 : d4 <= 16 ? 16 : 32;
-    const dim3 dgrid((unsigned)std::min<int64_t>(cdiv(total * lg, 256), 8192));
-#define YT_DELTA(L) hipLaunchKernelGGL(attn_delta_kernel<L>, dgrid, dim3(256), 0, s, ctx, dctx, ldo, delta, N, heads, Tq, d)
-    switch (lg) {
-        case 1: YT_DELTA(1); break;
-        case 2: YT_DELTA(2); break;
-        case 4: YT_DELTA(4); break;
-        case 8: YT_DELTA(8); break;
-        case 16: YT_DELTA(16); break;
-        default: YT_DELTA(32); break;
-    }
-#undef YT_DELTA
-}
-
 // ---- launches over one or two problems of equal (N, heads, d) ------------------------------------------------------------------
 static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
     const AttnArgs& a0 = b.p[0];
@@ -1424,11 +1343,9 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
         drop = drop || b.p[i].p_drop > 0.f;
         maxTq = std::max(maxTq, b.p[i].Tq); maxTk = std::max(maxTk, b.p[i].Tk);
     }
-    // one wave per workgroup and per SIMD (attn_fwd_w1_body); YTVLN_ATTN_W1=0: the two-wave form everywhere
-    static const int w1_on = env_int("YTVLN_ATTN_W1", 1);
-    static const int w1_d64 = env_int("YTVLN_ATTN_W1_D64", 1);          // 0: the one-wave kernels only for d = 128 (all three kernels)
-    const bool w1_dim = a0.d == 128 || (a0.d == 64 && w1_d64);             // unpadded heads the one-wave kernels are instantiated for
-    if (w1_on && w1_dim && !a0.bf16 && maxTk <= 512) {
+    // one wave per workgroup and per SIMD (attn_fwd_w1_body); option ATTN_W1 bit 0 clear: the two-wave form everywhere
+    const bool w1_dim = a0.d == 128 || a0.d == 64;             // unpadded heads the one-wave kernels are instantiated for
+    if ((opt(OPT_ATTN_W1) & 1) && w1_dim && !a0.bf16 && maxTk <= 512) {
         b.gx0 = (int)cdiv(b.p[0].Tq, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
@@ -1455,24 +1372,9 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
     b.nb0 = b.gx0 * a0.heads * a0.N;
     const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
     YT_REQUIRE(total < (1ll << 31), "attn_fwd: grid too large");
-    static const int dsplit_on = env_int("YTVLN_ATTN_DSPLIT", 1);
-    const bool dsplit = dsplit_on && dp == 128 && nw == 2 && !a0.bf16;
+    const bool dsplit = opt(OPT_ATTN_DSPLIT) && dp == 128 && nw == 2 && !a0.bf16;
     for (int i = 0; i < np; ++i) b.p[i].dsplit = dsplit;
     const size_t lds_bytes = lds_fwd(dp, maxTk) + (dsplit ? 4096 : 0);
-#ifdef YTVLN_ATTN_PROBES
-    static const int probe = env_int("YTVLN_ATTN_PROBE", 0);
-    if (probe && dp == 128 && drop && !a0.bf16) {
-#define YT_PROBE(P) case P: hipLaunchKernelGGL((attn_fwd_probe_kernel<P>), dim3((unsigned)total), dim3(64 * nw), lds_bytes, s, b); break
-        switch (probe) {
-            YT_PROBE(1); YT_PROBE(2); YT_PROBE(3); YT_PROBE(4); YT_PROBE(7); YT_PROBE(8); YT_PROBE(16); YT_PROBE(24); YT_PROBE(32); YT_PROBE(35);
-            YT_PROBE(39); YT_PROBE(31);
-            default: return fail(-1, "attn_fwd: unknown probe %d", probe);
-        }
-#undef YT_PROBE
-        YT_LAUNCH_CHECK("attn_fwd probe");
-        return 0;
-    }
-#endif
     YT_DISPATCH(attn_fwd_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_bytes, s, b);
     YT_LAUNCH_CHECK("attn_fwd");
     return 0;
@@ -1493,16 +1395,11 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         maxTq = std::max(maxTq, a.Tq); maxTk = std::max(maxTk, a.Tk);
     }
     // delta[n,h,q] = sum_c dctx.ctx is produced by the dQ kernel's prologue (it owns the query rows) and read by the dK/dV kernel that
-    // follows it on the stream; YTVLN_ATTN_DELTA_KERNEL=1 restores the separate pass
-    static const int delta_kernel = env_int("YTVLN_ATTN_DELTA_KERNEL", 0);
-    for (int i = 0; i < np; ++i) {
-        if (delta_kernel) launch_delta(b.p[i].ctx, b.p[i].dctx, b.p[i].ldo, const_cast<float*>(b.p[i].delta), a0.N, a0.heads, b.p[i].Tq, a0.d, s);
-        b.p[i].delta_out = delta_kernel ? nullptr : const_cast<float*>(b.p[i].delta);
-    }
+    // follows it on the stream
+    for (int i = 0; i < np; ++i) b.p[i].delta_out = const_cast<float*>(b.p[i].delta);
     {
-        static const int w1_on = env_int("YTVLN_ATTN_W1_DQ", 1);          // one wave per workgroup and per SIMD (attn_bwd_dq_w1_body); 0: the two-wave form
-        static const int w1_d64 = env_int("YTVLN_ATTN_W1_D64", 1);
-        const bool w1 = w1_on && (a0.d == 128 || (a0.d == 64 && w1_d64)) && !a0.bf16 && !delta_kernel && maxTk <= 512;      // (unpadded heads, delta produced here, mask row in registers)
+        // one wave per workgroup and per SIMD (attn_bwd_dq_w1_body); option ATTN_W1 bit 1 clear: the two-wave form
+        const bool w1 = (opt(OPT_ATTN_W1) & 2) && (a0.d == 128 || a0.d == 64) && !a0.bf16 && maxTk <= 512;      // (unpadded heads, mask row in registers)
         const int nw = w1 ? 1 : pick_waves(maxTq, a0.d);
         b.gx0 = (int)cdiv(b.p[0].Tq, 32 * nw);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32 * nw) : 1;
@@ -1512,15 +1409,13 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         if (w1) YT_W1(attn_bwd_dq_w1_kernel, lds_fwd(dp, maxTk));
         else YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
     }
-    // one wave per workgroup and per SIMD (attn_bwd_dkv_w1_body; YTVLN_ATTN_W1_DKV=0: always the wave-pair form): unpadded fp32 heads, lse / delta
-    // rows staged by one wave, and at least two rounds of the 1024 wave slots (a 1.3-round launch -- 3 key tiles x 448 heads -- pays for 2:
-    // there the pair form, whose workgroups are half as long, loses less)
-    static const int w1_dkv_on = env_int("YTVLN_ATTN_W1_DKV", 1);
-    static const int w1_dkv_d64 = env_int("YTVLN_ATTN_W1_D64", 1);
+    // one wave per workgroup and per SIMD (attn_bwd_dkv_w1_body; option ATTN_W1 bit 2 clear: always the wave-pair form): unpadded fp32 heads, lse /
+    // delta rows staged by one wave, and at least two rounds of the 1024 wave slots (a 1.3-round launch -- 3 key tiles x 448 heads -- pays for 2:
+    // there the pair form, whose workgroups are half as long, loses less; option ATTN_W1_DKV_ANY = 1 takes the one-wave form regardless)
     const int64_t w1_waves = (cdiv(b.p[0].Tk, 32) + (np > 1 ? cdiv(b.p[1].Tk, 32) : 0)) * a0.heads * a0.N;
     const int64_t w1_slots = a0.d == 128 ? 1024 : 2048;          // (d = 64: 17 KB of LDS and < 256 registers per wave -> two per SIMD)
     const bool w1_fill = w1_waves * 100 >= cdiv(w1_waves, w1_slots) * w1_slots * 85;      // the last round at least ~85 % useful overall
-    if (w1_dkv_on && (a0.d == 128 || (a0.d == 64 && w1_dkv_d64)) && !a0.bf16 && maxTq <= 512 && (w1_fill || w1_dkv_on == 2)) {
+    if ((opt(OPT_ATTN_W1) & 4) && (a0.d == 128 || a0.d == 64) && !a0.bf16 && maxTq <= 512 && (w1_fill || opt(OPT_ATTN_W1_DKV_ANY))) {
         b.gx0 = (int)cdiv(b.p[0].Tk, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;

@@ -27,6 +27,22 @@ int fail(int code, const char* fmt, ...);
         if (e_ != hipSuccess) return ::ytvln::fail(-2, "%s: %s", name, hipGetErrorString(e_));  \
     } while (0)
 
+// ---- run-time options (ytvln_set_option / ytvln_get_option; misc.hip holds the table) ----------------------------------------------
+// The complete list of switches the library reads.  Each one starts from the environment variable YTVLN_<NAME> (read once, at first
+// use) and can be changed at run time through the C ABI; INTEGRATION.md documents every entry and tests/test_abi.py checks that its
+// table and this one agree.
+enum Option {
+    OPT_ATTN_W1 = 0,         // bit mask of the one-wave-per-SIMD attention kernels: 1 forward, 2 dQ, 4 dK/dV (default 7; 0 = two-wave forms)
+    OPT_ATTN_W1_DKV_ANY,     // 1: the one-wave dK/dV kernel for launches of any size (default 0: only when its last round of wave slots is >= 85 % full)
+    OPT_ATTN_DSPLIT,         // 1 (default): two-wave forward workgroups holding a single query tile split the head dimension between their waves
+    OPT_GEMM_TILE,           // -1 (default): planner; 0..4 forces 128x128 / 128x64 / 64x64 / 256x128 / 256x256 where legal
+    OPT_GEMM_SPLITS,         // -1 (default): planner; n forces the split-K count where split-K is legal
+    OPT_GEMM_SPLIT_MAP,      // 1 (default): split-K workgroups laid out split-major per XCD; 0: split-fastest (same results, more fabric traffic)
+    OPT_GEMM_GENERIC,        // 1: every fp32 GEMM on the register-staged generic kernel (default 0)
+    OPT_COUNT
+};
+int opt(int id);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

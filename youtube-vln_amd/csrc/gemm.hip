@@ -37,13 +37,10 @@ struct GemmArgs {
     int Kloop;            // contraction length the fast kernel iterates over (K rounded up to 32 when A's K tail is zero-padded)
     int mnA, mnB;         // clamp extents of the operands in their M / N dimension (rounded up to 4 inside padding)
     int ktail;            // 1: the last k-tile reaches past K -> M/N-contiguous operands clamp their k rows to K-1
-    int* sk_flags;        // stream-K: one arrival flag per workgroup (zeroed before the launch); partials live in ws
     int x3;               // 1: fp32 operands split into three bf16 terms in registers, six bf16 MFMAs per product (YTVLN_GEMM_SPLIT_BF16X3)
     float* asum;          // optional: asum[m] = sum_k op(A)[m, k] (bias gradient riding on the weight-gradient GEMM); M-contiguous A, LDS-DMA path only
     float* asum_ws;       // split-K: per-split partial row sums [splits][M], reduced in a fixed order by splitk_reduce_kernel
     int split_map;        // 1: split-K workgroups are laid out split-major per XCD (see decode_tile)
-    unsigned long long* dbg;  // YTVLN_GEMM_DBG: per-workgroup clocks {entry, loop start, loop end, exit} (s_memrealtime, 100 MHz) + shader cycles of the loop
-    int probe;            // timing probes of gemm_sw_kernel (YTVLN_GEMM_PROBE; wrong results by construction): 1 no operand DMA, 2 no LDS fragment reads
 };
 
 constexpr int BK = 32;
@@ -191,9 +188,6 @@ __device__ __forceinline__ void epilogue_body(const GemmArgs& g, f32x16 (&acc)[T
                     cp0[(int64_t)dr * g.ldc] = v;
                 }
             }
-            // big wave tiles (gemm_sw_kernel: up to 4 x 4 sub-tiles, accumulators in AGPRs): without a fence hipcc hoists the accumulator
-            // reads and address arithmetic of ALL sub-tiles to the top and spills them to scratch
-            if constexpr (TM * TN > 8) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -470,8 +464,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
     };
 
-    unsigned long long dbg_t0 = 0, dbg_c0 = 0;
-    if (g.dbg) { dbg_t0 = __builtin_amdgcn_s_memrealtime(); dbg_c0 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t);
@@ -559,8 +551,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
         }
     }
-    unsigned long long dbg_t2 = 0, dbg_c2 = 0;
-    if (g.dbg) { dbg_t2 = __builtin_amdgcn_s_memrealtime(); dbg_c2 = __builtin_amdgcn_s_memtime(); }
     if constexpr (!A_KC && !BF16 && !X3) {
         if (do_asum) {
 #pragma unroll
@@ -575,394 +565,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
     }
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
-    if (g.dbg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
-            d[0] = dbg_t0; d[1] = dbg_t0; d[2] = dbg_t2; d[3] = t3; d[4] = dbg_c2 - dbg_c0; d[5] = 0; d[6] = nk;
-        }
-    }
-}
-
-// Epilogue of the big-wave-tile kernels (gemm_sw_kernel): the wave's accumulators go through LDS (the operand ring is free by then) so that
-// the output leaves as 16-byte row segments -- one global_store_dwordx4 per lane covers two (TN = 4) or four (TN = 2) 512 / 256-byte row
-// pieces per wave instruction instead of sixteen 4-byte stores per 32 x 32 sub-tile -- and so that bias / activation / beta work runs in a
-// small run-time loop over rows instead of a fully unrolled, ten-times specialised store sequence (the unrolled form of a 4 x 4 sub-tile
-// wave is ~1 MB of code per kernel and spills).  `wlds`: this wave's private LDS region, 64 x (32 TN) floats; two passes for TM = 4.
-// Same arithmetic per element as epilogue_body (bias add, then activation, then beta * old), so results are bit-identical.
-// (`stage(PASS)` writes rows [PROWS * pass, PROWS * (pass + 1)) of the wave tile into wlds[row][W] -- the only part that knows the accumulator layout)
-template <int W, int PROWS, int NPASS, class Stage>
-__device__ __forceinline__ void epilogue_lds_rows(const GemmArgs& g, float* __restrict__ wlds, int row0, int col0, int lane, int split, Stage&& stage) {
-    constexpr int W4 = W / 4;                           // 16-byte groups per staged row
-    constexpr int RPI = 64 / W4;                        // rows covered by one wave-wide 16-byte access
-    const bool partial = g.splits > 1;
-    float* const Cb = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
-    const int64_t ldc = partial ? g.N : g.ldc;
-    const int epi = partial ? YTVLN_EPI_NONE : g.epilogue;
-    const float beta = partial ? 0.f : g.beta;
-    const float* bias = partial ? nullptr : g.bias;
-    const int c4 = lane % W4, rsub = lane / W4;
-    const int col = col0 + 4 * c4;
-    const bool vec = (g.N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 &&
-                     (epi == YTVLN_EPI_NONE || epi == YTVLN_EPI_RELU || g.aux == nullptr ||
-                      ((g.ldaux & 3) == 0 && (reinterpret_cast<uintptr_t>(g.aux) & 15) == 0));
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = col + u < g.N ? bias[col + u] : 0.f;
-    }
-    static_for<NPASS>([&](auto PASS) __attribute__((always_inline)) {
-        stage(PASS);                                         // (compile-time pass index: a run-time one would move the accumulators to scratch memory)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int rbase = row0 + PROWS * decltype(PASS)::value;
-        auto rows = [&](auto EPI_TAG) __attribute__((always_inline)) {
-            constexpr int EPI = decltype(EPI_TAG)::value;
-            constexpr bool AUXLD = EPI == YTVLN_EPI_MUL_DGELU || EPI == YTVLN_EPI_MUL_DRELU;
-            constexpr int NIT = PROWS / RPI, CH = 8;             // CH row accesses at a time: their global loads are in flight together
-            static_assert(NIT % CH == 0, "chunking");
-            for (int it0 = 0; it0 < NIT; it0 += CH) {
-                float4 t[CH], o[CH], a[CH];
-                if (vec) {
-                    if (beta != 0.f) {
-#pragma unroll
-                        for (int c = 0; c < CH; ++c) {
-                            const int row = rbase + (it0 + c) * RPI + rsub;
-                            o[c] = (row < g.M && col < g.N) ? *reinterpret_cast<const float4*>(Cb + (int64_t)row * ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
-                    if constexpr (AUXLD) {
-#pragma unroll
-                        for (int c = 0; c < CH; ++c) {
-                            const int row = rbase + (it0 + c) * RPI + rsub;
-                            a[c] = (row < g.M && col < g.N) ? *reinterpret_cast<const float4*>(g.aux + (int64_t)row * g.ldaux + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < CH; ++c) t[c] = *reinterpret_cast<const float4*>(wlds + ((it0 + c) * RPI + rsub) * W + 4 * c4);
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int row = rbase + (it0 + c) * RPI + rsub;
-                    if (row >= g.M || col >= g.N) continue;
-                    float v[4] = {t[c].x + bv[0], t[c].y + bv[1], t[c].z + bv[2], t[c].w + bv[3]};
-                    float* cp = Cb + (int64_t)row * ldc + col;
-                    float* xp = (EPI == YTVLN_EPI_GELU || AUXLD) ? g.aux + (int64_t)row * g.ldaux + col : nullptr;
-                    if (vec) {
-                        if constexpr (EPI == YTVLN_EPI_GELU) {
-                            if (g.aux) *reinterpret_cast<float4*>(xp) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) v[u] = gelu_erf(v[u]);
-                        } else if constexpr (EPI == YTVLN_EPI_RELU) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
-                        } else if constexpr (EPI == YTVLN_EPI_MUL_DGELU) {
-                            v[0] *= dgelu_erf(a[c].x); v[1] *= dgelu_erf(a[c].y); v[2] *= dgelu_erf(a[c].z); v[3] *= dgelu_erf(a[c].w);
-                        } else if constexpr (EPI == YTVLN_EPI_MUL_DRELU) {
-                            v[0] = a[c].x > 0.f ? v[0] : 0.f; v[1] = a[c].y > 0.f ? v[1] : 0.f; v[2] = a[c].z > 0.f ? v[2] : 0.f; v[3] = a[c].w > 0.f ? v[3] : 0.f;
-                        }
-                        if (beta != 0.f) { v[0] += beta * o[c].x; v[1] += beta * o[c].y; v[2] += beta * o[c].z; v[3] += beta * o[c].w; }
-                        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (col + u >= g.N) continue;
-                            float x = v[u];
-                            if constexpr (EPI == YTVLN_EPI_GELU) { if (g.aux) xp[u] = x; x = gelu_erf(x); }
-                            else if constexpr (EPI == YTVLN_EPI_RELU) x = fmaxf(x, 0.f);
-                            else if constexpr (EPI == YTVLN_EPI_MUL_DGELU) x *= dgelu_erf(xp[u]);
-                            else if constexpr (EPI == YTVLN_EPI_MUL_DRELU) x = xp[u] > 0.f ? x : 0.f;
-                            if (beta != 0.f) x += beta * cp[u];
-                            cp[u] = x;
-                        }
-                    }
-                }
-            }
-        };
-        switch (epi) {
-            case YTVLN_EPI_GELU: rows(std::integral_constant<int, YTVLN_EPI_GELU>{}); break;
-            case YTVLN_EPI_RELU: rows(std::integral_constant<int, YTVLN_EPI_RELU>{}); break;
-            case YTVLN_EPI_MUL_DGELU: rows(std::integral_constant<int, YTVLN_EPI_MUL_DGELU>{}); break;
-            case YTVLN_EPI_MUL_DRELU: rows(std::integral_constant<int, YTVLN_EPI_MUL_DRELU>{}); break;
-            default: rows(std::integral_constant<int, YTVLN_EPI_NONE>{}); break;
-        }
-    });
-}
-
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* __restrict__ wlds, int row0, int col0, int lane, int split) {
-    constexpr int W = 32 * TN, IB = TM >= 2 ? 2 : 1;    // floats per staged row; 32-row blocks per pass
-    const int l31 = lane & 31, half = lane >> 5;
-    epilogue_lds_rows<W, 32 * IB, TM / IB>(g, wlds, row0, col0, lane, split, [&](auto PASS) __attribute__((always_inline)) {
-        constexpr int i0 = decltype(PASS)::value * IB;
-#pragma unroll
-        for (int ii = 0; ii < IB; ++ii)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    wlds[(32 * ii + (r & 3) + 8 * (r >> 2) + 4 * half) * W + 32 * j + l31] = acc[i0 + ii][j][r];
-    });
-}
-
-// ---- one wave per SIMD, software-pipelined main loop (round 3) -----------------------------------------------------------------------
-// What the round-3 probes measured (tools/lab/gen_mfma_lds_bench.py, profiles/round3_pp_probes.log): while one wave of a SIMD
-// streams fp32 matrix instructions, the OTHER wave of that SIMD gets about one vector-memory / LDS / VALU instruction issued per matrix
-// instruction (64 cycles) -- a 35-instruction operand-load phase takes ~2100-2300 cycles beside a 2048-cycle matrix phase, which is what
-// holds gemm_dma_kernel (and the ping-pong form above) at 0.80-0.90 of the matrix peak.  The same instructions placed INSIDE the
-// matrix-issuing wave's own stream cost ~3 cycles per ds_read_b128 and ~11 per LDS-DMA piece.  Hence this form: four waves per workgroup,
-// one per SIMD, one workgroup per CU, up to 512 registers per lane; a wave's operand fragments are double-buffered in registers at
-// k-group granularity (4 k per group, 4 groups per 32-deep k-tile) and every fragment read / DMA issue is interleaved one behind a matrix
-// instruction (sched_group_barrier).  ONE workgroup barrier per k-tile, between k-groups 2 and 3:
-//   group 0..2 of tile t : matrix instructions of group g on F[g & 1]  ||  reads of group g + 1 -> F[(g + 1) & 1]
-//   before the barrier   : own DMA pieces of tile t + 1 retired (counted vmcnt), own reads of (t, group 3) retired (lgkmcnt(0))
-//   group 3 of tile t    : matrix instructions on F[1]  ||  DMA of tile t + NS into the slot of tile t (every wave is done reading it)
-//                                                       ||  reads of (t + 1, group 0) -> F[0]
-// so NS slots keep NS - 1 tiles of DMA in flight under a full tile of matrix work each.
-// Cross-XCD exchange of stream-K partial tiles without cache-wide fences (guide, section 5.7): write-through (sc1) 16-byte stores,
-// vmcnt drain, workgroup barrier, ONE relaxed agent-scope flag store; the owner polls the flag relaxed (an acquire poll would invalidate
-// its L1 on every iteration) and reads the slab with sc1 loads.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_sc1(float* p, v4f v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ v4f load_sc1(const float* p) {      // the caller waits (s_waitcnt vmcnt(0)) before using the value
-    v4f v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-// The main loop of the one-wave-per-SIMD kernels as a callable: k-tiles [kbeg / 32, kbeg / 32 + nk) of the block tile at (m0, n0) are
-// accumulated into `acc` (zeroed by the caller).  On return no DMA is in flight and this wave has read everything it needed from the ring;
-// the caller puts a workgroup barrier between two calls (and before it reuses the ring as epilogue staging space).
-template <int BM, int BN, bool A_KC, bool B_KC, int NS>
-struct SwLoop {
-    static constexpr int NW = 4, KB = 32;
-    using TA = DmaTile<BM, A_KC, NW, KB>;
-    using TB = DmaTile<BN, B_KC, NW, KB>;
-    static constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;  // waves 2 (m) x 2 (n)
-    static constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
-    static constexpr int NPT = TA::NI + TB::NI;
-    static constexpr int NMF = TM * TN * 4;                    // matrix instructions per k-group
-    static_assert(NS >= 2 && NS <= 4 && NS * STAGE * 4 <= 160 * 1024, "ring does not fit the LDS");
-
-    __device__ static __forceinline__ void run(const GemmArgs& g, float* __restrict__ smem, int m0, int n0, int kbeg, int nk, bool tail_here,
-                                               f32x16 (&acc)[TM][TN], float (&asum)[TM], bool do_asum, int wave, int lane,
-                                               unsigned long long* dbg_t1, unsigned long long* dbg_c1) {
-        const int l31 = lane & 31, half = lane >> 5;
-        const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-        const float* pa[TA::NI];
-        const float* pb[TB::NI];
-    #pragma unroll
-        for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg, wave, lane, i, 0x7fffffff);
-    #pragma unroll
-        for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg, wave, lane, i, 0x7fffffff);
-        const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
-
-        int st_in = 0;
-        auto issue = [&](int kt) {
-            float* As = smem + st_in * STAGE;
-            float* Bs = As + SA;
-            st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
-            if (tail_here && kbeg + (kt + 1) * KB > g.K) {
-    #pragma unroll
-                for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + kt * KB, wave, lane, i, g.K - 1);
-    #pragma unroll
-                for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + kt * KB, wave, lane, i, g.K - 1);
-            }
-    #pragma unroll
-            for (int i = 0; i < TA::NI; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
-                pa[i] += sa;
-            }
-    #pragma unroll
-            for (int i = 0; i < TB::NI; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
-                pb[i] += sb;
-            }
-        };
-        auto retire = [&](int left) {         // wait for this wave's oldest outstanding tile; `left` younger tiles stay in flight
-            if (NS >= 4 && left >= 2) wait_vmcnt<2 * NPT>();
-            else if (NS >= 3 && left >= 1) wait_vmcnt<NPT>();
-            else wait_vmcnt<0>();
-        };
-
-        float4 fa[2][TM], fb[2][TN];
-        constexpr int NFR = TM + TN;                        // fragments per k-group
-        static_assert(NFR + NPT <= NMF, "more loads than matrix instructions in a k-group");
-        // (every register-array index below is a compile-time constant: a run-time index makes hipcc move the fragment arrays to scratch LDS)
-        // fragment R of k-group sg: the A fragments first, then the B fragments (one ds_read_b128, or four ds_read_b32 of a k-major image)
-        auto rd1 = [&](auto BUF, auto R, const float* __restrict__ As, const float* __restrict__ Bs, int sg) __attribute__((always_inline)) {
-            constexpr int buf = decltype(BUF)::value, r = decltype(R)::value;
-            if constexpr (r < TM) fa[buf][r] = TA::frag(As, wm0, r, l31, half, sg);
-            else fb[buf][r - TM] = TB::frag(Bs, wn0, r - TM, l31, half, sg);
-        };
-        auto mma1 = [&](auto BUF, auto K) __attribute__((always_inline)) {      // matrix instruction K of a group: k-major, accumulators alternate
-            constexpr int buf = decltype(BUF)::value, k = decltype(K)::value;
-            constexpr int c = k / (TM * TN), i = (k / TN) % TM, j = k % TN;
-            const float av = c == 0 ? fa[buf][i].x : c == 1 ? fa[buf][i].y : c == 2 ? fa[buf][i].z : fa[buf][i].w;
-            const float bv = c == 0 ? fb[buf][j].x : c == 1 ? fb[buf][j].y : c == 2 ? fb[buf][j].z : fb[buf][j].w;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-        };
-        // One k-group: matrix instruction k on F[CUR], then (pinned behind it) fragment k of the NEXT group into F[CUR ^ 1], then -- group 3 of a
-        // steady tile -- DMA piece k - NFR of tile kt + NS.  sched_barrier(0) after every step: the order IS the schedule.
-        auto group = [&](auto CUR, auto DMA_TAG, const float* __restrict__ As, const float* __restrict__ Bs, int sg_next, bool reads, float* Ad) __attribute__((always_inline)) {
-            constexpr int cur = decltype(CUR)::value;
-            constexpr bool DMA = decltype(DMA_TAG)::value;
-            if constexpr (!A_KC) {
-                if (do_asum) {
-    #pragma unroll
-                    for (int i = 0; i < TM; ++i) asum[i] += (fa[cur][i].x + fa[cur][i].y) + (fa[cur][i].z + fa[cur][i].w);
-                }
-            }
-            static_for<NMF>([&](auto K) __attribute__((always_inline)) {
-                constexpr int k = decltype(K)::value;
-                mma1(CUR, K);
-                if constexpr (k < NFR) {
-                    if (reads && !(g.probe & 2)) rd1(std::integral_constant<int, cur ^ 1>{}, K, As, Bs, sg_next);
-                }
-                if constexpr (DMA && k >= NFR && k - NFR < TA::NI) {
-                    constexpr int d = k - NFR;
-                    if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[d], (lds_ptr_t)(Ad + (wave * TA::NI + d) * 256), 16, 0, 0);
-                    pa[d] += sa;
-                } else if constexpr (DMA && k >= NFR + TA::NI && k - NFR < NPT) {
-                    constexpr int e = k - NFR - TA::NI;
-                    if (!(g.probe & 1)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[e], (lds_ptr_t)(Ad + SA + (wave * TB::NI + e) * 256), 16, 0, 0);
-                    pb[e] += sb;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-
-        const int npro = min(nk, NS);
-        for (int t = 0; t < npro; ++t) issue(t);
-        retire(npro - 1);
-        __builtin_amdgcn_s_barrier();
-        if (g.dbg && dbg_t1) { *dbg_t1 = __builtin_amdgcn_s_memrealtime(); *dbg_c1 = __builtin_amdgcn_s_memtime(); }
-        static_for<NFR>([&](auto R) __attribute__((always_inline)) { rd1(I0{}, R, smem, smem + SA, 0); });
-
-        int st_out = 0;
-        // STEADY tiles (every tile but the last NS + 1) have no K tail, always issue tile kt + NS and always read tile kt + 1: their body is
-        // ONE basic block, so the DMA issues and the next tile's first reads sit between the matrix instructions of k-group 3.
-        auto tile = [&](auto steady_tag, int kt) __attribute__((always_inline)) {
-            constexpr bool STEADY = decltype(steady_tag)::value;
-            const float* As = smem + st_out * STAGE;
-            const float* Bs = As + SA;
-            st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
-            const float* An = smem + st_out * STAGE;      // next tile's slot
-            group(I0{}, std::false_type{}, As, Bs, 1, true, nullptr);
-            group(I1{}, std::false_type{}, As, Bs, 2, true, nullptr);
-            group(I0{}, std::false_type{}, As, Bs, 3, true, nullptr);
-            if constexpr (STEADY) wait_vmcnt<(NS - 2) * NPT>();       // my pieces of tile kt + 1; tiles kt + 2 .. kt + NS - 1 stay in flight
-            else if (kt + 1 < nk) retire(min(NS - 2, nk - 2 - kt));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of (kt, group 3): the slot may be overwritten behind the barrier
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (STEADY) {
-                float* Ad = smem + st_in * STAGE;
-                st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
-                group(I1{}, std::true_type{}, An, An + SA, 0, true, Ad);
-            } else {
-                if (kt + NS < nk) issue(kt + NS);
-                group(I1{}, std::false_type{}, An, An + SA, 0, kt + 1 < nk, nullptr);
-            }
-        };
-        int kt = 0;
-        for (; kt < nk - NS - 1; ++kt) tile(std::true_type{}, kt);
-        for (; kt < nk; ++kt) tile(std::false_type{}, kt);
-    }
-};
-
-template <int BM, int BN, bool A_KC, bool B_KC, int NS>
-__global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const GemmArgs g) {
-    using L = SwLoop<BM, BN, A_KC, B_KC, NS>;
-    constexpr int TM = L::TM, TN = L::TN, KB = L::KB;
-    __shared__ __attribute__((aligned(16))) float smem[NS * L::STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits, g.split_map);
-    const int m0 = tc.m * BM, n0 = tc.n * BN;
-    const int kbeg = tc.split * g.kchunk;
-    const int kend = min(g.Kloop, kbeg + g.kchunk);
-    const int nk = (kend - kbeg) / KB;
-    const bool tail_here = g.ktail && kend == g.Kloop;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const bool do_asum = !A_KC && g.asum != nullptr && tc.n == 0 && (wave & 1) == 0;
-    float asum[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
-
-    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_c1 = 0;
-    if (g.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
-    L::run(g, smem, m0, n0, kbeg, nk, tail_here, acc, asum, do_asum, wave, lane, &dbg_t1, &dbg_c1);
-    if constexpr (!A_KC) {
-        if (do_asum) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float v = asum[i] + __shfl_xor(asum[i], 32, 64);
-                const int row = m0 + wm0 + 32 * i + l31;
-                if (half == 0 && row < g.M) {
-                    if (g.splits > 1) g.asum_ws[(int64_t)tc.split * g.M + row] = v;
-                    else g.asum[row] = v;
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_s_barrier();        // every wave is done reading the ring (and no DMA is in flight): it becomes the epilogue's staging space
-    unsigned long long dbg_t2 = 0, dbg_c2 = 0;
-    if (g.dbg) { dbg_t2 = __builtin_amdgcn_s_memrealtime(); dbg_c2 = __builtin_amdgcn_s_memtime(); }
-    static_assert(4 * 64 * 32 * TN * 4 <= NS * L::STAGE * 4, "epilogue staging does not fit the ring");
-    epilogue_lds<TM, TN>(g, acc, smem + wave * (64 * 32 * TN), m0 + wm0, n0 + wn0, lane, tc.split);
-    if (g.dbg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
-            d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = t3; d[4] = dbg_c2 - dbg_c1;
-            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            d[5] = ((unsigned long long)xcc << 32) | hwid; d[6] = nk;
-        }
-    }
 }
 
 // The three-term (X3) kernels are instantiated in their own translation unit -- gemm_x3.hip includes this file with YT_GEMM_X3_TU
 // defined -- so that the two halves of the GEMM code compile in parallel.  128x128 tiles run as 4 waves of 64x64 there (two workgroups
 // per CU: 7.3 instead of 11 VALU ops per MFMA, 154 -> 166 TFLOP/s on 16128x1024x1024 forced onto that tile).
 void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s);
-// The one-wave-per-SIMD kernels likewise (gemm_sw.hip, YT_GEMM_SW_TU).  Returns false when no instantiation exists for the tile.
-bool launch_sw(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s);
-
-#if defined(YT_GEMM_SW_TU)
-template <int BM, int BN, int NS>
-static void launch_sw_tile(const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
-    const dim3 gr(grid), blk(256);
-    if (!transA && transB) hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, true, true, NS>), gr, blk, 0, s, g);
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, true, false, NS>), gr, blk, 0, s, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, false, false, NS>), gr, blk, 0, s, g);
-    else hipLaunchKernelGGL((gemm_sw_kernel<BM, BN, false, true, NS>), gr, blk, 0, s, g);
-}
-bool launch_sw(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
-    if (bm == 128 && bn == 128) { launch_sw_tile<128, 128, 3>(g, transA, transB, grid, s); return true; }
-    if (bm == 256 && bn == 128) { launch_sw_tile<256, 128, 3>(g, transA, transB, grid, s); return true; }
-    if (bm == 256 && bn == 256) { launch_sw_tile<256, 256, 2>(g, transA, transB, grid, s); return true; }
-    return false;
-}
-}  // namespace ytvln
-#elif defined(YT_GEMM_X3_TU)
+#if defined(YT_GEMM_X3_TU)
 template <int BM, int BN, int NW, int WPS>
 static void launch_x3_tile(const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
     const dim3 gr(grid), blk(NW * 64);
@@ -978,139 +587,6 @@ void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsign
 }
 }  // namespace ytvln
 #else       // ---- everything below belongs to the main translation unit -------------------------------------------------------------
-
-// ---- stream-K ---------------------------------------------------------------------------------------------------------------------
-// For outputs whose 128x128 tile count does not fill whole waves of the 256 CUs (the 4480-row text-stream projections: 35 x 6 = 210
-// tiles = 82 % of one wave, 35 x 24 = 840 = 82 % of four).  The (tile, k-tile) iteration space, tile-major, is cut into gridDim equal
-// contiguous ranges, one per resident workgroup (gridDim <= 512, so all of them run concurrently).  A range may start or end inside
-// a tile:
-//   * a segment that does not start at k = 0 is a CONTRIBUTION: its accumulators go to ws[position] (fragment order) and the
-//     workgroup raises its flag (release, agent scope);
-//   * the workgroup whose segment starts at k = 0 OWNS the tile: if the segment stops short of K it waits for the flags of the
-//     following positions until the tile is covered, adds their partials in position order (deterministic) and runs the ordinary
-//     epilogue -- bias, GELU, ... work unchanged, unlike split-K.
-// A range visits the end of tile A first and the beginning of tile B last, so contributions are produced early and consumed late:
-// owners practically never spin.  Positions are XCD-remapped workgroup ids: neighbours in the iteration space share an L2.
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512, 4) void gemm_streamk_kernel(const GemmArgs g) {
-    constexpr int BM = 128, BN = 128, NW = 8, KB = 32, NS = 2;
-    using TA = DmaTile<BM, A_KC, NW, KB>;
-    using TB = DmaTile<BN, B_KC, NW, KB>;
-    constexpr int TM = 1, TN = 2;
-    constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
-    constexpr int NG = KB / 8;
-    __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
-    const int nkt = g.Kloop / KB;                                   // k-tiles per output tile
-    const int64_t total = (int64_t)g.ntiles * nkt;
-    const int G = gridDim.x;
-    const int pos = xcd_remap(blockIdx.x, G);
-    int64_t it = total * pos / G;
-    const int64_t it_end = total * (pos + 1) / G;
-    const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
-    float* myws = g.ws + (int64_t)pos * (BM * BN);
-
-    while (it < it_end) {
-        const int tile = (int)(it / nkt), k0 = (int)(it - (int64_t)tile * nkt);
-        const int k1 = (int)min((int64_t)nkt, it_end - (int64_t)tile * nkt);      // this segment: k-tiles [k0, k1) of `tile`
-        const TileCoord tc = tile_coord(tile, g.tiles_m, g.tiles_n);
-        const int m0 = tc.m * BM, n0 = tc.n * BN;
-        const float* pa[TA::NI];
-        const float* pb[TB::NI];
-#pragma unroll
-        for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, k0 * KB, wave, lane, i, 0x7fffffff);
-#pragma unroll
-        for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, k0 * KB, wave, lane, i, 0x7fffffff);
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-        const int nk = k1 - k0;
-        auto issue = [&](int kt) {
-            float* As = smem + (kt & 1) * STAGE;
-            float* Bs = As + SA;
-#pragma unroll
-            for (int i = 0; i < TA::NI; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
-                pa[i] += sa;
-            }
-#pragma unroll
-            for (int i = 0; i < TB::NI; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
-                pb[i] += sb;
-            }
-        };
-        __builtin_amdgcn_s_barrier();                 // the previous segment's last stage is no longer being read
-        issue(0);
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) issue(kt + 1);
-            const float* As = smem + (kt & 1) * STAGE;
-            const float* Bs = As + SA;
-#pragma unroll
-            for (int sg = 0; sg < NG; ++sg) {
-                float4 a[TM], b[TN];
-                a[0] = TA::frag(As, wm0, 0, l31, half, sg);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[j].x, acc[0][j], 0, 0, 0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[j].y, acc[0][j], 0, 0, 0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[j].z, acc[0][j], 0, 0, 0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[j].w, acc[0][j], 0, 0, 0);
-                }
-            }
-        }
-        if (k0 != 0) {
-            // contribution: fragment-order dump (lane-contiguous 16-byte write-through stores), then publish
-            float* dst = myws + (int64_t)tid * 32;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v4f v = {acc[0][j][4 * q], acc[0][j][4 * q + 1], acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]};
-                    store_sc1(dst + (j * 4 + q) * 4, v);
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(g.sk_flags + pos, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (k1 < nkt) {
-                // owner of a tile that other positions finish: gather their partials in position order
-                int covered = k1, p = pos + 1;
-                while (covered < nkt) {
-                    if (tid == 0)
-                        while (__hip_atomic_load(g.sk_flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
-                    __syncthreads();
-                    const float* src = g.ws + (int64_t)p * (BM * BN) + (int64_t)tid * 32;
-                    v4f part[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) part[u] = load_sc1(src + u * 4);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const v4f v = part[j * 4 + q];
-                            acc[0][j][4 * q] += v[0]; acc[0][j][4 * q + 1] += v[1]; acc[0][j][4 * q + 2] += v[2]; acc[0][j][4 * q + 3] += v[3];
-                        }
-                    // position p covers from its start to min(tile end, its own end)
-                    const int64_t pend = total * (p + 1) / G;
-                    covered = (int)min((int64_t)nkt, pend - (int64_t)tile * nkt);
-                    ++p;
-                }
-            }
-            gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, 0);
-        }
-        it = (int64_t)tile * nkt + k1;
-    }
-}
 
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
@@ -1162,8 +638,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //     per tile, the last workgroup to arrive adds them in split order.  Bit-identical to the separate pass, but one workgroup per output
 //     tile moves splits x tile bytes at a latency-bound ~50 GB/s while the separate pass uses the whole chip: 119.3 -> 119.7 ms per step
 //     when applied to launches with <= 4 splits, 122.4 with <= 8, 126.2 with all.  profiles/round3_fused_splitk.log.)
-struct Plan { int tile; int splits; int streamk; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
-constexpr int SK_GRID = 512;                 // stream-K workgroups: two per CU, all resident
+struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
 
 static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0, bool x3 = false, bool ta = false) {
     // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
@@ -1197,15 +672,13 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
 
 // big_ok: the 256-row tiles are only used with a K-contiguous A on the LDS-DMA path (an M-contiguous A needs four ds_read_b32 per
 // fragment and loses with the wide wave tiles: 121 -> 99 TFLOP/s on 30522x768x4480).
-static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool sk_ok = false, bool x3 = false, bool ta = false) {
-    Plan best = {0, 1, 0};
+static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bool x3 = false, bool ta = false) {
+    Plan best = {0, 1};
     double best_t = 1e30;
-    const int force_tile = getenv("YTVLN_GEMM_TILE") ? atoi(getenv("YTVLN_GEMM_TILE")) : -1;       // experiment knobs
-    const int force_sp = getenv("YTVLN_GEMM_SPLITS") ? atoi(getenv("YTVLN_GEMM_SPLITS")) : -1;
-    static const int big = getenv("YTVLN_GEMM_BIG") ? atoi(getenv("YTVLN_GEMM_BIG")) : 2;          // 0: no 256-row tiles, 1: 256x128 only
+    const int force_tile = opt(OPT_GEMM_TILE), force_sp = opt(OPT_GEMM_SPLITS);       // experiment knobs (-1: the planner decides)
     for (int tile = 0; tile < 5; ++tile) {
         if (force_tile >= 0 && tile != force_tile) continue;
-        if (tile >= 3 && (!big_ok || big < tile - 2 || M < 256)) continue;
+        if (tile >= 3 && (!big_ok || M < 256)) continue;
         if (ta && tile == 3) continue;          // (256x128 was never measured with an M-contiguous A)
         // split-K: 128x128 always; 256x256 in the three-term form and -- round 2 -- for the native weight-gradient layout (ta):
         // 1024x1024x16128 323 -> 305 us, 2048x1024x16128 551 -> 505, 768x3072x4480 190 -> 178 (16 x 16, 32 x 8, 36 x 7 workgroups)
@@ -1214,29 +687,13 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
             const double t = plan_cost(M, N, K, tile, sp, epilogue, x3, ta);
             // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
-            if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp, 0}; }
-        }
-    }
-    // stream-K over 128x128 tiles (gemm_streamk_kernel): every one of the 512 resident workgroups gets the same number of k-tiles, any
-    // epilogue.  Measured on the 4480- and 7680-row text shapes it fills the idle CUs (+22 %) but pays ~30-35 us per workgroup for the
-    // partial-tile round trip and the second pipeline fill, all workgroups in lock-step: 0.97x / 0.95x of the best ordinary plan.
-    // Kept as an opt-in (YTVLN_GEMM_STREAMK=1: when the model predicts a win, =2: whenever legal); off by default.
-    // Round 3 rebuilt the schedule on the one-wave-per-SIMD main loop (SwLoop, 0.87-0.90 of the pipe with one workgroup per CU): 0.90-1.0x of
-    // the default plans on every text shape (profiles/round3_streamk_sw.log) -- with all CUs busy the chip clocks down, so the
-    // idle 18 % of a 210-tile round is not recoverable throughput.  That kernel was removed again.
-    static const int sk_on = getenv("YTVLN_GEMM_STREAMK") ? atoi(getenv("YTVLN_GEMM_STREAMK")) : 0;
-    if (sk_ok && !x3 && sk_on && force_tile < 0 && force_sp < 0 && K % BK == 0) {
-        const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), nkt = K / BK;
-        if (tiles >= 96 && tiles * nkt >= 4 * SK_GRID) {
-            const double t = 35.0 + (double)cdiv(tiles * nkt, 256) * 2.3;
-            if (t < best_t * 0.95 || sk_on == 2) best = {0, 1, 1};
+            if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp}; }
         }
     }
     return best;
 }
 
 static int plan_splits(int M, int N, int K, int epilogue) { return plan_gemm(M, N, K, epilogue).splits; }
-static int64_t streamk_ws_elems() { return (int64_t)SK_GRID * 128 * 128 + SK_GRID; }     // partial tiles + flags
 
 // bf16 launches (K counted in 4-byte words): matrix time is 8x shorter, so the legacy occupancy rule (fill whole rounds of the 512
 // resident workgroups, at least 8 k-tiles per split) is kept for them.
@@ -1287,7 +744,6 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, KB, NS, WPS>), grid, blk, 0, s, g);   \
         else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, KB, NS, WPS>), grid, blk, 0, s, g);                           \
     } while (0)
-        static const int cfg = getenv("YTVLN_GEMM_CFG") ? atoi(getenv("YTVLN_GEMM_CFG")) : 0;
         // the tiles the three-term planner uses also exist in that form (YTVLN_GEMM_SPLIT_BF16X3): their own translation unit
         if (g.x3 && ((BM == 256 && BN == 256) || (BM == 128 && BN == 128) || (BM == 128 && BN == 64))) {
             launch_x3(BM, BN, g, transA, transB, grid.x, s);
@@ -1298,20 +754,12 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
-        // opt-in (YTVLN_GEMM_SW=1): the one-wave-per-SIMD software-pipelined kernels (gemm_sw_kernel) for the 128x128 / 256x128 / 256x256 tiles
-        //   1: every such launch; 2: only launches whose epilogue READS a second matrix (beta != 0, x GELU' / x ReLU'): there the LDS-staged
-        //      epilogue (16-byte row loads, 8 in flight per lane) beats the direct one (round-3 A/B, tools/r3_gpu12.sh)
-        static const int sw = getenv("YTVLN_GEMM_SW") ? atoi(getenv("YTVLN_GEMM_SW")) : 0;
-        const bool loads = g.splits == 1 && (g.beta != 0.f || g.epilogue == YTVLN_EPI_MUL_DGELU || g.epilogue == YTVLN_EPI_MUL_DRELU);
-        if (sw && (sw == 1 || loads) && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
         if constexpr (BM == 256 && BN == 256) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x64, one workgroup per CU (native instruction only, like 64x64)
         } else if constexpr (BM == 128 && BN == 128) {
-            if (cfg == 1) YT_DMA(8, 16, 4, 4);      // experiment knob: YTVLN_GEMM_CFG=1 -> 16-deep k-tiles, 4-stage ring
-            else if (cfg == 2 && g.Kloop % 64 == 0 && g.kchunk % 64 == 0) YT_DMA(8, 64, 2, 2);     // 64-deep k-tiles, one workgroup per CU
-            else YT_DMA(8, 32, 2, 4);
+            YT_DMA(8, 32, 2, 4);
         } else {
             YT_DMA(4, 32, 2, 2);
         }
@@ -1478,25 +926,10 @@ static void launch_bf16(GemmArgs& g, hipStream_t s, bool big_split = false) {
 
 using namespace ytvln;
 
-static int g_clock_probe = 0;
-static double g_clock_result[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
-extern "C" int ytvln_gemm_clock_probe(int enable) {
-    g_clock_probe = enable != 0;
-    return 0;
-}
-
-extern "C" int ytvln_gemm_clock_result(double* out8) {
-    YT_REQUIRE(out8 != nullptr, "gemm_clock_result: NULL output");
-    for (int i = 0; i < 8; ++i) out8[i] = g_clock_result[i];
-    return 0;
-}
-
 extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
     YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan: bad argument");
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
-    static const int big_ta = getenv("YTVLN_GEMM_BIG_TA") ? atoi(getenv("YTVLN_GEMM_BIG_TA")) : 1;
-    const Plan p = plan_gemm(M, N, K, epilogue, !transA || big_ta, false, false, transA && big_ta);
+    const Plan p = plan_gemm(M, N, K, epilogue, true, false, transA != 0);
     *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
     return 0;
 }
@@ -1505,20 +938,19 @@ extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue,
     YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan_x3: bad argument");
     (void)transA;       // the three-term form takes the 256-row tiles with either A layout (see ytvln_gemm_f32)
     static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
-    const Plan p = plan_gemm(M, N, K, epilogue, true, false, true);
+    const Plan p = plan_gemm(M, N, K, epilogue, true, true);
     *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
     return 0;
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
     bool big_unused = false;
-    const int splits = std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, false, true).splits),
-                                         std::max(plan_gemm(M, N, K, epilogue, false, false, true).splits,
-                                                  plan_gemm(M, N, K, epilogue, true, false, true).splits)),
+    const int splits = std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, true).splits),
+                                         std::max(plan_gemm(M, N, K, epilogue, false, true).splits,
+                                                  plan_gemm(M, N, K, epilogue, true, true).splits)),
                                 std::max(plan_splits_bf16(M, N, K, epilogue), plan_splits_bf16_any(M, N, K, epilogue, &big_unused)));
     // (covers both GEMM entry points, either A layout, the fp32x3 plans and both bf16 split rules)
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
-    if (plan_gemm(M, N, K, epilogue, true, true).streamk) need = std::max(need, streamk_ws_elems());
     return need;
 }
 
@@ -1540,22 +972,10 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
     hipStream_t s = as_stream(stream);
-    g.splits = 1; g.kchunk = K; g.ws = nullptr; g.sk_flags = nullptr;
+    g.splits = 1; g.kchunk = K; g.ws = nullptr;
     g.x3 = (flags & YTVLN_GEMM_SPLIT_BF16X3) != 0;
-    static const int split_map = getenv("YTVLN_GEMM_SPLIT_MAP") ? atoi(getenv("YTVLN_GEMM_SPLIT_MAP")) : 1;
-    g.split_map = split_map;
+    g.split_map = opt(OPT_GEMM_SPLIT_MAP);
     g.asum = nullptr; g.asum_ws = nullptr;
-    static const int probe = getenv("YTVLN_GEMM_PROBE") ? atoi(getenv("YTVLN_GEMM_PROBE")) : 0;
-    g.probe = probe;
-    static const int dbg_env = getenv("YTVLN_GEMM_DBG") ? atoi(getenv("YTVLN_GEMM_DBG")) : 0;     // n: print the clocks of call number n
-    static unsigned long long* dbg_buf = nullptr;
-    static int dbg_calls = 0;
-    const int dbg_on = dbg_env || g_clock_probe;
-    g.dbg = nullptr;
-    if (dbg_on) {
-        if (!dbg_buf) hipMalloc(&dbg_buf, 8192 * 8 * sizeof(unsigned long long));
-        g.dbg = dbg_buf;
-    }
     // Fast-path legality.  With YTVLN_GEMM_A_ZERO_PADDED the caller guarantees that A's contiguous dimension is followed by
     // readable ZERO padding up to lda: a K-contiguous A may then have K % 32 != 0 (the loop runs over the rounded-up K and
     // B's k rows are clamped -- B must be [K,N]), and an M-contiguous A may have M % 4 != 0.
@@ -1567,30 +987,11 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     bool ma_ok = !transA || (M % 4 == 0 && M >= 4);
     if (!ma_ok && apad && transA && lda >= m4 && M >= 4) { ma_ok = true; g.mnA = m4; }
     g.fast = (K > 0) && k_ok && g.vecA && g.vecB && ma_ok && (!transB ? (N % 4 == 0 && N >= 4) : true) &&
-             !getenv("YTVLN_GEMM_GENERIC");
-    // three-term form: the 256x256 tile also takes an M-contiguous A (the split's VALU work dominates the four ds_read_b32 per fragment)
-    // and split-K: 1024x1024x16128 144 -> 186, 4480x768x3072 136 -> 171 TFLOP/s (YTVLN_X3_BIG_TA=0 restores the native rule)
-    static const int x3_big_ta = getenv("YTVLN_X3_BIG_TA") ? atoi(getenv("YTVLN_X3_BIG_TA")) : 1;
-    // native instruction with an M-contiguous A (weight gradients): 256x256 tiles + split-K compete with 128x128 since round 2
-    // (YTVLN_GEMM_BIG_TA=0 restores the 128x128-only rule)
-    static const int big_ta = getenv("YTVLN_GEMM_BIG_TA") ? atoi(getenv("YTVLN_GEMM_BIG_TA")) : 1;
-    const bool ta_native = g.fast && transA && !g.x3 && big_ta;
-    Plan plan = plan_gemm(M, N, K, epilogue, g.fast && (!transA || (g.x3 && x3_big_ta) || ta_native),
-                          g.fast && !g.ktail && workspace && workspace_elems >= streamk_ws_elems(), g.x3 && g.fast, ta_native);
-    if (plan.streamk) {
-        g.tiles_m = (int)cdiv(M, 128); g.tiles_n = (int)cdiv(N, 128); g.ntiles = g.tiles_m * g.tiles_n;
-        g.splits = 1; g.kchunk = g.Kloop; g.ws = workspace;
-        g.sk_flags = reinterpret_cast<int*>(workspace + (int64_t)SK_GRID * 128 * 128);
-        hipMemsetAsync(g.sk_flags, 0, SK_GRID * sizeof(int), s);
-        static const int skg = getenv("YTVLN_GEMM_SKGRID") ? std::min(SK_GRID, std::max(8, atoi(getenv("YTVLN_GEMM_SKGRID")) / 8 * 8)) : 256;      // one workgroup per CU measured best (95.6 vs 88.5 TFLOP/s with two)
-        const dim3 grid(skg), blk(512);
-        if (!transA && transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, true>), grid, blk, 0, s, g);
-        else if (!transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<true, false>), grid, blk, 0, s, g);
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_streamk_kernel<false, false>), grid, blk, 0, s, g);
-        else hipLaunchKernelGGL((gemm_streamk_kernel<false, true>), grid, blk, 0, s, g);
-        YT_LAUNCH_CHECK("gemm_f32 (stream-K)");
-        return 0;
-    }
+             !opt(OPT_GEMM_GENERIC);
+    // the 256-row tiles take either A layout: K-contiguous (forward / input gradients) and M-contiguous (weight gradients; 256x256 + split-K
+    // competes with 128x128 since round 2), in the native and in the three-term form
+    const bool ta_native = g.fast && transA && !g.x3;
+    Plan plan = plan_gemm(M, N, K, epilogue, g.fast, g.x3 && g.fast, ta_native);
     const int want = plan.splits;
     // row sums of op(A) ride on launches that take the LDS-DMA main loop with an M-contiguous fp32 A and no K tail (a clamped tail row would
     // be counted twice); everything else reports "not done" and the caller runs ytvln_colsum_f32
@@ -1627,31 +1028,6 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
         else launch_tile<64, 64>(g, transA, transB, s);
     }
     YT_LAUNCH_CHECK("gemm_f32");
-    ++dbg_calls;
-    if ((dbg_env && dbg_calls == dbg_env) || g_clock_probe) {          // clock probe / debugging aid (synchronises the device)
-        hipDeviceSynchronize();
-        const int nb = g.ntiles * g.splits;
-        std::vector<unsigned long long> h((size_t)nb * 8);
-        hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull, t3 = 0;
-        double loop_us = 0, cyc = 0, pro = 0, epi = 0;
-        for (int b = 0; b < nb; ++b) { t0 = std::min(t0, h[(size_t)b * 8]); t3 = std::max(t3, h[(size_t)b * 8 + 3]); }
-        for (int b = 0; b < nb; ++b) {
-            const unsigned long long* d = &h[(size_t)b * 8];
-            loop_us += (d[2] - d[1]) * 0.01 / nb; cyc += (double)d[4] / nb; pro += (d[1] - d[0]) * 0.01 / nb; epi += (d[3] - d[2]) * 0.01 / nb;
-        }
-        const double mfma_cyc = 2.0 * (double)std::min(M, g.tiles_m * (M + g.tiles_m - 1) / g.tiles_m) * 0 + 0;
-        (void)mfma_cyc;
-        const double tile_cyc = (double)(M > 0 ? 1 : 1) * 0;
-        (void)tile_cyc;
-        const int bm = (int)cdiv(M, g.tiles_m), bn = (int)cdiv(N, g.tiles_n);       // (approximate tile extents)
-        const double ideal = (double)h[6] * 32.0 * ((bm + 31) / 32 * 32) * ((bn + 31) / 32 * 32) * 2.0 / 256.0;   // matrix-pipe cycles of one workgroup's loop
-        g_clock_result[0] = (t3 - t0) * 0.01; g_clock_result[1] = loop_us; g_clock_result[2] = cyc; g_clock_result[3] = ideal;
-        g_clock_result[4] = cyc / loop_us * 1e-3; g_clock_result[5] = (double)nb; g_clock_result[6] = pro; g_clock_result[7] = epi;
-        if (dbg_env)
-            fprintf(stderr, "gemmdbg %d x %d x %d tA%d tB%d: %d workgroups, kernel %.1f us, prologue %.1f, loop %.1f (%.0f cycles = %.3f of the matrix pipe, clock %.3f GHz), epilogue %.1f us\n",
-                    M, N, K, transA, transB, nb, (t3 - t0) * 0.01, pro, loop_us, cyc, ideal / cyc, cyc / loop_us * 1e-3, epi);
-    }
     return 0;
 }
 
@@ -1736,8 +1112,8 @@ extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t
     g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias = bias; g.aux = aux;
     g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
-    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.sk_flags = nullptr; g.x3 = 0;
-    g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1; g.probe = 0; g.dbg = nullptr;
+    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.x3 = 0;
+    g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1;
     g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
     bool big_split = false;
     int want = plan_splits_bf16_any(M, N, K / 2, epilogue, &big_split);

@@ -47,8 +47,10 @@ SIGNATURES = {
     "ytvln_attn_fwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
     "ytvln_attn_bwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
     "ytvln_gemm_plan": [I32, I32, I32, I32, I32, P, P, P],
-    "ytvln_gemm_clock_probe": [I32],
-    "ytvln_gemm_clock_result": [P],
+    "ytvln_option_count": [],
+    "ytvln_option_name": [I32],
+    "ytvln_set_option": [P, I32],
+    "ytvln_get_option": [P, P],
     "ytvln_gemm_plan_x3": [I32, I32, I32, I32, I32, P, P, P],
     "ytvln_cast_bf16_dual": [P, I64, I32, I32, P, I64, P, I64, P],
     "ytvln_cast_bf16_dual_colsum": [P, I64, I32, I32, P, I64, P, I64, P, P],
@@ -84,7 +86,7 @@ SIGNATURES = {
     "ytvln_rccl_async_error": [P],
     "ytvln_rccl_destroy": [P],
 }
-RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p}
+RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
 DT_F32, DT_F64, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128
@@ -140,3 +142,23 @@ def call(name: str, *args):
     rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {_lib.ytvln_last_error().decode(errors='replace')}")
+
+
+def options() -> dict:
+    """{name: current value} of every run-time option of the library (include/ytvln.h: ytvln_option_*)."""
+    lib = load()
+    out = {}
+    for i in range(lib.ytvln_option_count()):
+        name = lib.ytvln_option_name(i).decode()
+        v = C.c_int(0)
+        call("ytvln_get_option", name.encode(), C.byref(v))
+        out[name] = v.value
+    return out
+
+
+def set_option(name: str, value: int) -> int:
+    """Set a run-time option (kernel-form selection for tests / experiments); returns the previous value."""
+    prev = C.c_int(0)
+    call("ytvln_get_option", name.encode(), C.byref(prev))
+    call("ytvln_set_option", name.encode(), int(value))
+    return prev.value

@@ -324,8 +324,17 @@ class GradBucketReducer:
 _ACTIVE_DP = None        # weakref to the most recently built DataParallel: the data plane small logged-metric reductions ride on
 
 
-def metrics_world_size() -> int:
+def _active_dp():
+    """The DataParallel wrapper whose RCCL communicator the metric reductions ride on, or None: the most recently built one that still
+    has a live communicator (a closed wrapper -- `DataParallel.close()` -- falls back to torch.distributed)."""
     dp = _ACTIVE_DP() if _ACTIVE_DP is not None else None
+    if dp is None or dp.comm is None or not getattr(dp.comm, "_handle", None) or not dp.comm._handle.value:
+        return None
+    return dp
+
+
+def metrics_world_size() -> int:
+    dp = _active_dp()
     if dp is not None:
         return dp.world
     return dist.get_world_size() if dist.is_initialized() else 1
@@ -336,10 +345,15 @@ def metrics_all_reduce_(t: torch.Tensor) -> torch.Tensor:
     With the C ABI's communicator this is an RCCL call on the CURRENT stream -- no host round trip, capturable into a hipGraph; the
     torch.distributed default group (gloo when the gradients travel over `ytvln_rccl_*`) is only used when there is no communicator
     (the gloo path would synchronise the host in the middle of every train_step and cannot be stream-captured)."""
-    dp = _ACTIVE_DP() if _ACTIVE_DP is not None else None
-    if dp is not None and dp.comm is not None and t.is_cuda:
+    dp = _active_dp()
+    if dp is not None and t.is_cuda:
         if dp.world > 1 or dp.always_exchange:
-            dp.comm.all_reduce(t if t.is_contiguous() else t.contiguous(), "sum")
+            if t.is_contiguous():
+                dp.comm.all_reduce(t, "sum")
+            else:                      # RCCL reduces contiguous memory in place: go through a packed copy and write the sums back
+                tmp = t.contiguous()
+                dp.comm.all_reduce(tmp, "sum")
+                t.copy_(tmp)
         return t
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -437,6 +451,9 @@ class DataParallel(nn.Module):
             self._reducer = None
         if self.comm is not None:
             self.comm.close()
+        global _ACTIVE_DP
+        if _ACTIVE_DP is not None and _ACTIVE_DP() is self:
+            _ACTIVE_DP = None
 
 
 class GraphedTrainStep:
@@ -523,15 +540,21 @@ class GraphedTrainStep:
         """The phased form derives its exchange groups from what THIS rank observed while capturing; ranks that disagree would meet in
         mismatched ncclAllReduce calls -- a hang, not an error.  Compare a digest of (mode, slices) on the control plane and raise on
         every rank if they differ."""
-        self._verified = True
-        if not (dist.is_initialized() and self.world > 1):
-            return
-        mine = self.layout_digest()
-        every = [None] * dist.get_world_size(self.group)
-        dist.all_gather_object(every, mine, group=self.group)
-        if len(set(every)) != 1:
-            raise RuntimeError("GraphedTrainStep: ranks captured different gradient-exchange layouts "
-                               f"(mode {self.mode}; digests {sorted(set(every))}): refusing to start the exchange")
+        failed = getattr(self, "_layout_error", None)
+        if failed is not None:                 # sticky: a caller that swallowed the first error must not reach the mismatched collectives
+            raise RuntimeError(failed)
+        if self.world > 1 and not dist.is_initialized():
+            raise RuntimeError("GraphedTrainStep: world > 1 without a torch.distributed control plane -- the exchange layouts of the ranks "
+                               "cannot be compared before the first grouped collective")
+        if self.world > 1:
+            mine = self.layout_digest()
+            every = [None] * dist.get_world_size(self.group)
+            dist.all_gather_object(every, mine, group=self.group)
+            if len(set(every)) != 1:
+                self._layout_error = ("GraphedTrainStep: ranks captured different gradient-exchange layouts "
+                                      f"(mode {self.mode}; digests {sorted(set(every))}): refusing to start the exchange")
+                raise RuntimeError(self._layout_error)
+        self._verified = True                  # only after a successful comparison
 
     # ---- phased backward: the exchange overlaps the rest of the backward pass -----------------------------------------------------
     def _capture_phased(self, fwd_bwd, optimizer, flat, cap):

@@ -102,24 +102,32 @@ class DropoutState:
 
     @classmethod
     def get_state(cls) -> dict:
-        """{device string: (seed, counter)} of THIS process's current device -- one device->host read (checkpoint time only)."""
-        if not torch.cuda.is_available():
-            return {}
-        cur = torch.device("cuda", torch.cuda.current_device())
-        t = cls._global.get(cur)
-        if t is None:
-            return {}
-        return {str(cur): tuple(int(v) for v in t.tolist())}
+        """{device string: (seed, counter)} of every mask stream THIS process owns (one per device it ran a training-mode forward on; one
+        process per GPU: normally a single entry) -- one device->host read per entry, at checkpoint time only."""
+        return {str(dev): tuple(int(v) for v in t.tolist()) for dev, t in cls._global.items()}
 
     @classmethod
-    def set_state(cls, state: dict) -> None:
-        """Restore onto the caller's CURRENT device, whatever device string the checkpoint carries (one process per GPU: a checkpoint
-        written by rank 0 on cuda:0 is resumed by rank k on cuda:k and must not make it touch cuda:0 -- ADVICE r2).  A rank whose device
-        index differs from the saved one continues the saved counter on a seed shifted by the index difference, so the ranks' mask
-        streams stay distinct the way `set_seed(seed + local_rank)` made them (utils/misc.py:37-45)."""
+    def set_state(cls, state: dict, device=None) -> None:
+        """Restore a saved stream onto `device` -- default: the device of the one stream this process already owns, else the caller's
+        current device -- whatever device string the checkpoint carries (one process per GPU: a checkpoint written by rank 0 on cuda:0 is
+        resumed by rank k on cuda:k and must not make it touch cuda:0 -- ADVICE r2).  The entry saved under the target's own device string
+        is preferred; otherwise the first saved entry is taken and, when the device indices differ, its seed is shifted by the index
+        difference so that the ranks' mask streams stay distinct the way `set_seed(seed + local_rank)` made them (utils/misc.py:37-45).
+        Pass the model's device when it is not the current one."""
         if not state or not torch.cuda.is_available():
             return
-        cur = torch.device("cuda", torch.cuda.current_device())
+        if device is not None:
+            cur = torch.device(device)
+            if cur.type == "cuda" and cur.index is None:
+                cur = torch.device("cuda", torch.cuda.current_device())
+        elif len(cls._global) == 1:
+            cur = next(iter(cls._global))
+        else:
+            cur = torch.device("cuda", torch.cuda.current_device())
+            if cls._global and cur not in cls._global:
+                import warnings
+                warnings.warn(f"DropoutState.set_state: restoring onto the current device {cur} while this process owns streams on "
+                              f"{sorted(map(str, cls._global))}; pass device= to choose")
         key = str(cur) if str(cur) in state else sorted(state)[0]
         seed, counter = state[key]
         saved = torch.device(key)

@@ -54,7 +54,8 @@ def restore_checkpoint(path, model, optimizer, scheduler, logger=None) -> int:
             load(ckpt[key])
             say(f"load {key}...")
     if "ytvln_rng_state" in ckpt:
-        ops.DropoutState.set_state(ckpt["ytvln_rng_state"])
+        p0 = next(net.parameters(), None)          # the mask stream lives on the model's device, which need not be the current one
+        ops.DropoutState.set_state(ckpt["ytvln_rng_state"], device=p0.device if (p0 is not None and p0.is_cuda) else None)
     return ckpt["epoch"] + 1 if "epoch" in ckpt else 0
 
 
