@@ -122,6 +122,19 @@ class GemmTimer:
             return done
 
         ops._gemm = timed
+        inner_b = ops._gemm_bf16          # the bf16-resident path's projections (ytvln_gemm_bf16)
+
+        def timed_b(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw):
+            if not timer.on:
+                return inner_b(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            done = inner_b(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, **kw)
+            e1.record()
+            timer.records.append((e0, e1, M, N, K, int(transA), int(transB)))
+            return done
+
+        ops._gemm_bf16 = timed_b
 
     def summary(self):
         tot_ms, tot_flop, shapes = 0.0, 0.0, {}
@@ -174,8 +187,15 @@ class FamilyTimer:
                 return inner(name, *args)
             work = 0.0
             if fam == "layernorm":           # (.., rows, H, ..): 12 B read/written + 4 B saved per element forward, 20 B backward
-                rows, H = int(args[8]), int(args[9])
-                work = rows * H * (20.0 if "bwd" in name else 16.0)
+                if name == "ytvln_ln_bwd_bf16":          # bf16 rows: dy, s in; ds (and dx under dropout) out -> 8 B per element
+                    rows, H = int(args[9]), int(args[10])
+                    work = rows * H * 8.0
+                elif name.endswith("_bf16"):             # x, res in; y, s out -> 8 B per element
+                    rows, H = int(args[8]), int(args[9])
+                    work = rows * H * 8.0
+                else:
+                    rows, H = int(args[8]), int(args[9])
+                    work = rows * H * (20.0 if "bwd" in name else 16.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = inner(name, *args)
@@ -602,7 +622,7 @@ def main():
         "metric": "pretrain samples/sec (traj-instr pairs)", "value": round(value, 3), "unit": "pairs/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * elapsed / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate / activations / master weights",
+        "dtype": {"fp32": "f32", "bf16": "bf16 activations / gradients / weight copies in HBM, bf16 MFMA, f32 accumulate / softmax / LayerNorm statistics / logits / master weights / optimizer",
                   "fp32x3": "f32 operands split exactly into 3 bf16 terms in registers, 6 bf16 MFMAs per product, f32 accumulate (projections); "
                             "f32 everywhere else"}[a.precision], "data": "synthetic",
         "config": {"workload": a.workload, **({"gradient_exchange": ("ytvln_rccl_* (C ABI, " + os.path.basename(runner.comm.library) + ")") if runner.comm is not None
@@ -648,7 +668,7 @@ def main():
         # fp32x3: six bf16 matrix instructions per algorithmic product -> the ceiling for algorithmic FLOPs is the bf16 peak / 6
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32x3": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}[a.precision]
         kname = {"fp32": "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)",
-                 "bf16": "ytvln::gemm_dma_kernel<bf16> (v_mfma_f32_32x32x16_bf16) + bf16 operand staging kernels",
+                 "bf16": "ytvln::gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16; bf16 operands read in place, transposed operands by ds_read_b64_tr_b16)",
                  "fp32x3": "ytvln::gemm_dma_kernel<X3> (6 x v_mfma_f32_32x32x16_bf16 per product; peak = bf16 dense peak / 6)"}[a.precision]
         if a.precision != "fp32":
             traffic, traffic_note = None, None
@@ -680,7 +700,7 @@ def main():
         if "layernorm" in fsum:
             fms, fbytes, fn = fsum["layernorm"]
             fams["layernorm"] = {"bound": "hbm", "ms_per_step": round(fms / nsteps_prof, 3), "launches_per_step": round(fn / nsteps_prof, 1),
-                                 "work_per_step": round(fbytes / nsteps_prof / 1e9, 3), "work_unit": "GB algorithmic (16 B/element forward incl. the saved sum, 20 B backward)",
+                                 "work_per_step": round(fbytes / nsteps_prof / 1e9, 3), "work_unit": "GB algorithmic (fp32: 16 B/element forward incl. the saved sum, 20 B backward; bf16 rows: 8 B/element)",
                                  "achieved": round(fbytes / (fms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fbytes / (fms * 1e-3) / 1e9 / 8000.0, 4)}
         if "adamw" in fsum:
             fms, _, fn = fsum["adamw"]
@@ -754,8 +774,8 @@ def main():
         try:        # bf16 operands on the MFMA (the arithmetic of BASELINE configs[4], the reference's --amp analogue) at the headline shape
             vb, msb = time_variant("bf16", a.warmup + a.steps + 16)
             out.setdefault("variants", {})["bf16"] = {"value": vb, "unit": "pairs/s", "ms_per_step": msb,
-                                                      "note": "opt-in --precision bf16, not the headline: bf16-staged projections and bf16-operand "
-                                                              "attention, f32 accumulate / activations / master weights (parity: the cfg-5 goldens, bf16 bar)"}
+                                                      "note": "opt-in --precision bf16, not the headline: the bf16-resident path (bf16 activations / gradients / weight copies, "
+                                                              "f32 accumulate, softmax, statistics, logits, master weights; parity: the cfg-5 goldens, bf16 bar)"}
         except Exception as e:
             out.setdefault("variants", {})["bf16"] = {"error": f"{type(e).__name__}: {e}"}
         finally:

@@ -112,27 +112,23 @@ int ytvln_scatter_add_rows_f32(const float* x, int64_t ldx, const int64_t* idx, 
 int ytvln_scatter_add_rows_sorted_f32(const float* x, int64_t ldx, const int64_t* sorted_idx, const int64_t* perm, int M, int H,
                                       float* table_grad, int64_t skip_idx, void* stream);
 
-/* Mixed-precision variant of the dense projections (BASELINE config 5: "bf16 MFMA path"): fp32 tensors everywhere in HBM, bf16
- * operands staged per GEMM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 output and epilogue.  Opt-in (ytvln.ops
- * .set_matmul_precision("bf16")); the default path and the headline numbers are fp32 (ytvln_gemm_f32).
- *   ytvln_cast_bf16:  out = bf16(x), round-to-nearest-even; x is [rows, cols] fp32 (ldx).  transpose = 0 -> out [rows][ldo] (the
- *     contraction index is x's column); transpose = 1 -> out [cols][ldo] with out[c][r] = x[r][c] (contraction index = x's row).
- *     ldo = contraction length rounded up to 64, tail zero-filled.
- *   ytvln_gemm_bf16_nt:  C[M,N] (+)= A[M,K] . B[N,K]^T with A, B staged as above (K = the padded contraction length, % 64 == 0);
- *     bias / aux / epilogue / beta / workspace exactly as ytvln_gemm_f32 (workspace sized by ytvln_gemm_workspace_elems(M,N,K/2,epi)). */
-int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpose, uint16_t* out, int64_t ldo, void* stream);
-/* both stagings of one matrix in one pass (x read once): out_plain [rows][ld_plain] and out_t [cols][ld_t] -- a gradient dY is the A operand of
- * the input-gradient GEMM in the first form and of the weight-gradient GEMM in the second */
-int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain, uint16_t* out_t, int64_t ld_t,
-                         void* stream);
-/* the same staging, also leaving colsum_part[b][c] = sum over the 64 rows of row block b of x[.][c]  (b < ceil(rows/64), c < cols; fixed
- * summation order): first stage of the bias gradient db = colsum(dY) in bf16 mode, finished by ytvln_colsum_f32 over the partials
- * (the reference's bias gradient is autograd's sum over rows of dY, torch.nn.Linear as used in vilbert/vilbert.py:266-268 etc.) */
-int ytvln_cast_bf16_dual_colsum(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain, uint16_t* out_t,
-                                int64_t ld_t, float* colsum_part, void* stream);
-int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
-                       float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
-                       int64_t workspace_elems, void* stream);
+/* The bf16-resident path (BASELINE configs[4], ytvln.ops.set_matmul_precision("bf16")): activations, gradients and a bf16 copy of the
+ * weights live in HBM as bf16 and every projection reads its operands IN PLACE -- no per-call staging, cast or transpose:
+ *   C[M,N] (+)= op(A)[M,K] . op(B)[K,N]   with the transA / transB conventions of ytvln_gemm_f32 (bf16 elements, leading dimensions in elements);
+ *   an operand whose contraction index is its row (transA = 1, transB = 0) is gathered from LDS by ds_read_b64_tr_b16.
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16; bias is fp32; the epilogue runs in fp32 and rounds once (RNE) into C, which is bf16
+ * (c_dtype = YTVLN_DT_BF16) or fp32 (YTVLN_DT_F32: logits, pooled heads, weight gradients); aux (GELU pre-activation out, GELU' / ReLU' in) is
+ * bf16.  workspace: ytvln_gemm_bf16_workspace_elems(M,N,K,epilogue) floats (deterministic split-K of the weight gradients); flags:
+ * YTVLN_GEMM_A_ZERO_PADDED as for ytvln_gemm_f32, padding in units of 8 elements.  a_rowsum / rowsum_done (may both be NULL): as
+ * ytvln_gemm_f32_rowsum -- row sums of a k-major A (the bias gradient riding on the weight-gradient GEMM), fp32.
+ * Operands that are not 16-byte aligned with leading dimensions % 8 == 0 (tiny configurations) run a slow generic kernel: same results. */
+int64_t ytvln_gemm_bf16_workspace_elems(int M, int N, int K, int epilogue);
+int ytvln_gemm_bf16(const uint16_t* A, int64_t lda, int transA, const uint16_t* B, int64_t ldb, int transB, void* C, int64_t ldc,
+                    int c_dtype, const float* bias, uint16_t* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta,
+                    float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done, void* stream);
+/* out[r][c] = bf16(x[r][c]), round to nearest even: network inputs that arrive as fp32 (the 2048-d region features, once per step) and
+ * parameters that are not inside the optimizer's arenas yet (the steps before the first optimizer step). */
+int ytvln_cast_f32_bf16(const float* x, int64_t ldx, int64_t rows, int cols, uint16_t* out, int64_t ldo, void* stream);
 
 /* On-device batch preparation: the masking the reference applies per item on the host.
  *   ytvln_randomize_tokens  = randomize_tokens (utils/dataset/common.py:213-270, mask_action_rate = 0):  p = U[0,1) * mask;
@@ -189,6 +185,23 @@ int ytvln_act_bwd_f32(const float* dy, const float* aux, float* dz, int64_t n, i
 /* y = x * keep / (1 - p): nn.Dropout forward and (applied to dy) backward (lily.py:100). */
 int ytvln_dropout_f32(const float* x, float* y, int64_t n, float p, const int64_t* rng, int64_t site, void* stream);
 
+/* bf16-resident forms of the five kernels above (BASELINE configs[4]): rows of x / res / y / s_out / dy / s / ds / dx are bf16 (8-byte aligned),
+ * the arithmetic is the fp32 one (values widened on load, rounded to nearest even on store), statistics, gamma / beta, their gradient partials and
+ * the embedding tables stay fp32; the dropout masks are the SAME as in the fp32 kernels (one Philox draw per group of four elements).
+ * ytvln_ln_bwd_bf16: ds / dx may be NULL when the caller only wants ds_f32, an fp32 copy of ds for the embedding-table gradient kernels. */
+int ytvln_ln_fwd_bf16(const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, uint16_t* y, uint16_t* s_out, float* mean,
+                      float* rstd, int64_t rows, int H, float eps, float p_pre, float p_post, const int64_t* rng, int64_t site, void* stream);
+int ytvln_ln_bwd_bf16(const uint16_t* dy, const uint16_t* s, const float* mean, const float* rstd, const float* gamma, uint16_t* ds, uint16_t* dx,
+                      float* ds_f32, float* partial, int64_t rows, int H, float p_pre, float p_post, const int64_t* rng, int64_t site, void* stream);
+int ytvln_text_embed_fwd_bf16(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos, const float* type,
+                              const float* gamma, const float* beta, uint16_t* y, uint16_t* s_out, float* mean, float* rstd, int64_t rows,
+                              int T, int H, float eps, float p_post, const int64_t* rng, int64_t site, void* stream);
+int ytvln_image_embed_fwd_bf16(const uint16_t* img, const float* loc, const float* W5, const float* b5, const float* W4, const float* b4,
+                               const float* W2, const float* b2, const float* E, const float* gamma, const float* beta, uint16_t* y,
+                               uint16_t* s_out, float* mean, float* rstd, int64_t rows, int H, float eps, float p_post, const int64_t* rng,
+                               int64_t site, void* stream);
+int ytvln_act_bwd_bf16(const uint16_t* dy, const uint16_t* aux, uint16_t* dz, int64_t n, int act, void* stream);
+
 /* Fused multi-head attention on the fp32 matrix cores, flash-style (scores never reach HBM).  One entry point serves
  * BertSelfAttention (vilbert.py:284-311), BertImageSelfAttention (:413-440) and both directions of BertBiAttention
  * (:577-616):   ctx[n, i, h*d:(h+1)*d] = softmax_j(q_i.k_j * scale + mask[n, j]) (dropout) . v_j
@@ -207,24 +220,11 @@ int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
                        int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng, int64_t site,
                        void* stream);
 
-/* bf16-operand variants of the two attention entry points (opt-in bf16 MFMA path, BASELINE config 5): identical arguments, layouts and
- * fp32 tensors; inside the kernels the QK^T, PV and gradient contractions run on v_mfma_f32_32x32x16_bf16 with the operands rounded to
- * bf16 on the way from LDS / registers, fp32 accumulation, fp32 softmax.  Head dim must be a multiple of 8. */
-int ytvln_attn_fwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                        const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
-                        int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream);
-int ytvln_attn_bwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                        const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
-                        float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
-                        int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
-                        int64_t site, void* stream);
-
 /* Both directions of BertBiAttention (vilbert.py:552-618) in ONE launch per kernel: text queries over region keys/values and region
  * queries over text keys/values are independent problems of complementary shape (T x R and R x T); one grid holds the workgroups of
  * both, so the slots one direction's last partial round would leave idle are filled by the other.  Each problem is described like the
  * arguments of ytvln_attn_fwd_f32 / ytvln_attn_bwd_f32 (forward reads q,k,v,mask and writes ctx,lse; backward reads
- * q,k,v,mask,ctx_in,dctx,lse_in and writes delta,dq,dk,dv); N, heads, d, scale, rng and the operand precision are shared.  Falls back to
- * two ordinary launches when the two problems need different workgroup shapes. */
+ * q,k,v,mask,ctx_in,dctx,lse_in and writes delta,dq,dk,dv); N, heads, d, scale and rng are shared. */
 typedef struct ytvln_attn_problem {
     const float *q, *k, *v, *mask;
     const float *ctx_in, *dctx, *lse_in;
@@ -236,9 +236,18 @@ typedef struct ytvln_attn_problem {
     int64_t site;
 } ytvln_attn_problem;
 int ytvln_attn_fwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
-                        const int64_t* rng, int bf16, void* stream);
+                        const int64_t* rng, void* stream);
 int ytvln_attn_bwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
-                        const int64_t* rng, int bf16, void* stream);
+                        const int64_t* rng, void* stream);
+/* The same attention for the bf16-resident path (BASELINE configs[4]): in the problem records q, k, v, ctx, ctx_in, dctx, dq, dk, dv point to
+ * BF16 tensors (leading dimensions in elements), mask / lse / lse_in / delta stay fp32; every contraction runs on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation and fp32 softmax, the transposed operands (V^T.P^T, K^T.dS^T, Q^T.dS, dO^T.P) are gathered from the row-major LDS
+ * tiles by ds_read_b64_tr_b16.  `b` may be NULL (one problem: self-attention) or the second direction of BertBiAttention.  Head dimension
+ * 64 or 128. */
+int ytvln_attn_fwd_bf16(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
+                        const int64_t* rng, void* stream);
+int ytvln_attn_bwd_bf16(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
+                        const int64_t* rng, void* stream);
 
 /* probs[n,h,i,j] = exp(q_i.k_j*scale + mask - lse): the attention_probs tensor the reference returns when
  * output_all_attention_masks=True (vilbert.py:300, 311).  Diagnostic path, not on the training step. */
@@ -252,6 +261,10 @@ int ytvln_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* target, int
                      float* row_loss, float* out, int M, int V, void* stream);
 int ytvln_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
                      const float* out, const float* gout, float* dlogits, int64_t ldd, int M, int V, void* stream);
+/* the same gradient rounded to bf16, with ZEROS written to the padding columns [V, ldd): the buffer feeds ytvln_gemm_bf16 as a zero-padded
+ * operand (YTVLN_GEMM_A_ZERO_PADDED) as it stands (bf16-resident path) */
+int ytvln_ce_bwd_bf16(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
+                      const float* out, const float* gout, uint16_t* dlogits, int64_t ldd, int M, int V, void* stream);
 
 /* Masked KL of utils_init.py:117-128: sum_rows mask * sum_c t*(log t - log_softmax(pred)) / max(1, sum mask). */
 int ytvln_kl_fwd_f32(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask,
@@ -259,6 +272,8 @@ int ytvln_kl_fwd_f32(const float* pred, int64_t ld, const float* target, int64_t
 int ytvln_kl_bwd_f32(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask,
                      const float* row_lse, const float* out, const float* gout, float* dpred, int64_t ldd, int M,
                      int C, void* stream);
+int ytvln_kl_bwd_bf16(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, const float* row_lse,
+                      const float* out, const float* gout, uint16_t* dpred, int64_t ldd, int M, int C, void* stream);   /* bf16 + zeroed padding, as ytvln_ce_bwd_bf16 */
 
 /* F.binary_cross_entropy_with_logits(x, t, pos_weight) with mean reduction (utils_init.py:143, 160-161). n <= 65536.
  * pos_weight is a DEVICE scalar or NULL.  bwd writes dx. */
@@ -273,6 +288,10 @@ int ytvln_bce_bwd_f32(const float* x, const float* t, const float* pos_weight, c
  * grad_scale multiplies g on the fly (1/world_size after a summed all-reduce). */
 int ytvln_adamw_f32(float* p, const float* g, float* m, float* v, const void* chunks, int nchunks, const float* hyper,
                     float grad_scale, void* stream);
+/* the same step, ALSO writing bf16(p) (round to nearest even) at the same offsets of a bf16 arena: the weight operands of the bf16-resident
+ * path are refreshed by the optimizer step itself (+2 bytes per parameter, no cast pass) */
+int ytvln_adamw_f32_bf16copy(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, const void* chunks, int nchunks,
+                             const float* hyper, float grad_scale, void* stream);
 
 /* ---- data-parallel gradient exchange: RCCL over xGMI ------------------------------------------------------------------------
  * Replaces DistributedDataParallel over NCCL (utils/distributed.py:63-104: init_process_group("nccl") + DDP's bucketed all-reduce).

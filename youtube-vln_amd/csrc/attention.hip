@@ -44,7 +44,6 @@ struct AttnArgs {
     int N, heads, Tq, Tk, d;
     float scale, p_drop;
     const int64_t* rng; int64_t site;
-    int bf16;          // 1: bf16 MFMA operands (ytvln_attn_*_bf16 entry points)
     int dsplit;        // 1: single-tile two-wave workgroups run the d-split form (the launch reserved the 4 KB exchange buffer)
 };
 
@@ -112,22 +111,11 @@ __device__ __forceinline__ float4 lds4(const float* __restrict__ p) { return *re
 __device__ __forceinline__ float2 lds2(const float* __restrict__ p) { return *reinterpret_cast<const float2*>(p); }
 
 // per-lane operand registers: X[row0 + (lane&31)][half*(DP/2) + s], s = 0..DP/2-1 (zero past nrows / past d)
-template <int DP, bool BRANCHY = false>
+template <int DP>
 __device__ __forceinline__ void load_rowfrag(float (&R)[DP / 2], const float* __restrict__ base, int64_t ld, int64_t row_base,
                                              int row, int nrows, int col0, int d, int half) {
-    if constexpr (BRANCHY) {      // the form used until round 3: fewer registers in flight -- kept for the bf16 backward kernels (see below)
-#pragma unroll
-    for (int s4 = 0; s4 < DP / 2; s4 += 4) {
-        const int col = half * (DP / 2) + s4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nrows && col < d) v = *reinterpret_cast<const float4*>(base + (row_base + row) * ld + col0 + col);
-        R[s4] = v.x; R[s4 + 1] = v.y; R[s4 + 2] = v.z; R[s4 + 3] = v.w;
-    }
-    return;
-    }
     // branch-free: a load under a per-lane condition is followed by a wait at the join, which serialises the DP/8 loads of a fragment (one
-    // memory round trip EACH in every kernel's prologue); clamped addresses + a select keep them all in flight together.  Not for the bf16
-    // backward kernels: with all loads of a fragment live at once they spill (cfg-5 shapes: backward 3.37 -> 4.70 ms; tools/r3_bf16_attn.sh)
+    // memory round trip EACH in every kernel's prologue); clamped addresses + a select keep them all in flight together
     const bool rok = row < nrows;
     const float* __restrict__ rp = base + (row_base + (rok ? row : nrows - 1)) * ld + col0;
     float4 v[DP / 8];
@@ -155,35 +143,13 @@ __device__ __forceinline__ void load_rowfrag_raw(float (&R)[DP / 2], const float
     }
 }
 
-// bf16-operand variants (opt-in "bf16 MFMA path", BASELINE config 5): tiles and register fragments stay fp32; eight consecutive
-// contraction values of a lane are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on the way into ONE v_mfma_f32_32x32x16_bf16 where the
-// fp32 path issues eight 32x32x2 instructions.  Accumulators, softmax, lse / delta and every stored tensor remain fp32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 pack8(float a, float b, float c, float d, float e, float f, float g, float h) {
-    bf16x8 v;
-    v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
-    v[4] = (__bf16)e; v[5] = (__bf16)f; v[6] = (__bf16)g; v[7] = (__bf16)h;
-    return v;
-}
-#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
 // acc (32x32)[tile row][lane's own row] = Xs-tile (A: rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T (B: registers)
-template <int DP, bool BF = false, int PIPE = 0>
+template <int DP, int PIPE = 0>
 __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (BF) {
-#pragma unroll
-        for (int s8 = 0; s8 < DP / 2; s8 += 8) {       // this half-wave's contraction values s8 .. s8+7 (two 16-byte granules of the row)
-            const int g0 = s8 >> 2, g1 = g0 + 1;
-            const float4 x0 = lds4(Xs + lo.rows[g0 & 7] + (g0 & ~7) * 4);
-            const float4 x1 = lds4(Xs + lo.rows[g1 & 7] + (g1 & ~7) * 4);
-            acc = MFMA_BF(pack8(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w),
-                          pack8(R[s8], R[s8 + 1], R[s8 + 2], R[s8 + 3], R[s8 + 4], R[s8 + 5], R[s8 + 6], R[s8 + 7]), acc);
-        }
-        return acc;
-    } else if constexpr (PIPE > 0) {
+    if constexpr (PIPE > 0) {
         // LDS reads in batches of PIPE granules, batch b+1 issued between the matrix instructions of batch b: one exposed LDS latency per
         // call instead of one per pair of reads (hipcc on its own waits for every pair right where it issues it).  Costs ~2 x PIPE live
         // registers more than the compiler's order: 8 in the forward kernel, 4 where the register budget is tight.
@@ -222,27 +188,10 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 
 // acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
 //                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
-template <int DP, bool BF = false, int PIPE = 0>
+template <int DP, int PIPE = 0>
 __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo) {
     constexpr int NJ = DP / 32;
-    if constexpr (BF) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {          // tile rows krow(8s .. 8s+7, half): the order the P registers hold them
-            float x[8][NJ];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = 8 * s + i;
-                const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
-                if constexpr (NJ == 4) { const float4 v = lds4(p); x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w; }
-                else if constexpr (NJ == 2) { const float2 v = lds2(p); x[i][0] = v.x; x[i][1] = v.y; }
-                else x[i][0] = *p;
-            }
-            const bf16x8 a = pack8(P[8 * s], P[8 * s + 1], P[8 * s + 2], P[8 * s + 3], P[8 * s + 4], P[8 * s + 5], P[8 * s + 6], P[8 * s + 7]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                acc[j] = MFMA_BF(a, pack8(x[0][j], x[1][j], x[2][j], x[3][j], x[4][j], x[5][j], x[6][j], x[7][j]), acc[j]);
-        }
-    } else if constexpr (PIPE > 0) {
+    if constexpr (PIPE > 0) {
         // tile rows krow(r, half), r = 0..15, in batches of PIPE reads (see mma_rows)
         constexpr int HB = PIPE > 16 ? 16 : PIPE, NB = 16 / HB;
         auto rd = [&](int r, float (&v)[NJ]) {
@@ -316,10 +265,10 @@ __device__ __forceinline__ void store_rows(const f32x16 (&acc)[DP / 32], float* 
 template <int DP, bool DROP>
 __device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const int bx, const int h, const int n);      // below
 
-template <int DP, bool DROP, bool BF>
+template <int DP, bool DROP>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP, NJ = DP / 32;
-    if constexpr (DP == 128 && !BF) {
+    if constexpr (DP == 128) {
         // a two-wave workgroup holding a single query tile shares it between its waves (d-split form above); workgroup-uniform
         if (a.dsplit && blockDim.x == 128 && (bx * 2 + 1) * 32 >= a.Tq) {
             attn_fwd_dsplit_body<DP, DROP>(a, bx, h, n);
@@ -369,7 +318,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
         TILE_WAIT_AND_SYNC();
         Tile<DP>::issue(Vs, vb, ldv, j0, a.Tk, a.d, wave, nw, lane);
         if (active) {
-            const f32x16 S = mma_rows<DP, BF, 8>(Ks, Qr, lo);
+            const f32x16 S = mma_rows<DP, 8>(Ks, Qr, lo);
             float mt = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -411,7 +360,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, const int bx, c
         }
         TILE_WAIT_AND_SYNC();
         if (t + 1 < ntiles) Tile<DP>::issue(Ks, kb, ldk, j0 + 32, a.Tk, a.d, wave, nw, lane);
-        if (active) mma_regs_rows<DP, BF, 8>(O, P, Vs, lo);
+        if (active) mma_regs_rows<DP, 8>(O, P, Vs, lo);
     }
     if (active) {
         const float inv = 1.0f / l;
@@ -580,7 +529,7 @@ __device__ __forceinline__ void attn_fwd_dsplit_body(const AttnArgs& a, const in
 // dQ.  LDS as in the forward.  Per key tile t:
 //     wait+barrier (V(t) landed, everyone finished dS.K(t-1)) -> DMA K(t)   | dP^T = V(t).dO^T
 //     wait+barrier (K(t) landed, everyone finished V(t).dO^T) -> DMA V(t+1) | S^T = K(t).Q^T, dS, dQ += dS.K(t)
-template <int DP, bool DROP, bool BF>
+template <int DP, bool DROP>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -605,15 +554,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     Tile<DP>::issue(Vs, vb, ldv, 0, a.Tk, a.d, wave, nw, lane);      // V(0) travels while the register fragments are fetched
 
     float Qr[DP / 2], Gr[DP / 2];
-    load_rowfrag<DP, BF>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+    load_rowfrag<DP>(Gr, a.dctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
     const int64_t sidx = ((int64_t)n * a.heads + h) * a.Tq + qi;
     float dl;
     {
         // delta = sum_c dO[q][c] * O[q][c] for this lane's query (each half-wave holds half of the head dimension); written for the dK/dV
         // kernel, which follows on the stream
         float Cr[DP / 2];          // the O fragment: dead before the accumulators come alive; all three fragments' loads fly together
-        load_rowfrag<DP, BF>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
-        load_rowfrag<DP, BF>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        load_rowfrag<DP>(Cr, a.ctx, a.ldo, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
+        load_rowfrag<DP>(Qr, a.q, a.ldq, (int64_t)n * a.Tq, qi, a.Tq, col0, a.d, half);
         float acc = 0.f;
 #pragma unroll
         for (int s4 = 0; s4 < DP / 2; s4 += 4) acc += (Cr[s4] * Gr[s4] + Cr[s4 + 1] * Gr[s4 + 1]) + (Cr[s4 + 2] * Gr[s4 + 2] + Cr[s4 + 3] * Gr[s4 + 3]);
@@ -639,11 +588,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
         const int j0 = t * 32;
         TILE_WAIT_AND_SYNC();
         Tile<DP>::issue(Ks, kb, ldk, j0, a.Tk, a.d, wave, nw, lane);
-        if (active) dP = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Vs, Gr, lo);
+        if (active) dP = mma_rows<DP, YT_ATTN_BWD_PIPE>(Vs, Gr, lo);
         TILE_WAIT_AND_SYNC();
         if (t + 1 < ntiles) Tile<DP>::issue(Vs, vb, ldv, j0 + 32, a.Tk, a.d, wave, nw, lane);
         if (active) {
-            const f32x16 S = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Ks, Qr, lo);
+            const f32x16 S = mma_rows<DP, YT_ATTN_BWD_PIPE>(Ks, Qr, lo);
             float dS[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -658,7 +607,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
                     dS[r] = p * (dp - dl);
                 }
             }
-            mma_regs_rows<DP, BF, YT_ATTN_BWD_PIPE>(dQ, dS, Ks, lo);
+            mma_regs_rows<DP, YT_ATTN_BWD_PIPE>(dQ, dS, Ks, lo);
         }
     }
     if (active) store_rows<DP>(dQ, a.dq, a.lddq, (int64_t)n * a.Tq, q0, a.Tq, col0, a.d, l31, half, a.scale);
@@ -779,7 +728,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // K(t); V(t) (DP/8 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else w1_wait<DP / 8>();
-        const f32x16 S = mma_rows<DP, false, W1_PIPE>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, W1_PIPE>(Ks, Qr, lo);
         asm volatile("" ::: "memory");
         if (more) ks.issue(j0 + 32);
         if constexpr (FIRST) {
@@ -825,7 +774,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // V(t); K(t+1), if there is one, may still be on its way
         if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mma_regs_rows<DP, false, W1_PIPE>(O, P, Vs, lo);
+        mma_regs_rows<DP, W1_PIPE>(O, P, Vs, lo);
         asm volatile("" ::: "memory");
         if (more) vs.issue(j0 + 32);
     };
@@ -934,14 +883,14 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
         // V(t).  Behind it in the queue: K(t) (DP/8 pieces); in the first tile K(0) and dO (needed now as well), then Q and O
         if (FIRST) w1_wait<2 * (DP / 8)>();
         else w1_wait<DP / 8>();
-        const f32x16 dP = mma_rows<DP, false, W1_PIPE>(Vs, Gr, lo);
+        const f32x16 dP = mma_rows<DP, W1_PIPE>(Vs, Gr, lo);
         asm volatile("" ::: "memory");
         if (more) vtile(j0 + 32);
         // K(t) (and, in the first tile, Q).  Behind them: V(t+1) if there is one, and in the first tile the O fragment
         if (FIRST) { if (more) w1_wait<2 * (DP / 8)>(); else w1_wait<DP / 8>(); }
         else if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const f32x16 S = mma_rows<DP, false, W1_PIPE>(Ks, Qr, lo);
+        const f32x16 S = mma_rows<DP, W1_PIPE>(Ks, Qr, lo);
         if constexpr (FIRST) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -969,7 +918,7 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
                 dS[r] = p * (dp - dl);
             }
         }
-        mma_regs_rows<DP, false, W1_PIPE>(dQ, dS, Ks, lo);
+        mma_regs_rows<DP, W1_PIPE>(dQ, dS, Ks, lo);
         asm volatile("" ::: "memory");
         if (more) ktile(j0 + 32);
     };
@@ -986,7 +935,7 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
 //     barrier
 //     S-wave: dV += (P o keep)^T . dO                      D-wave: dS = P o (dP o keep - delta), dK += dS^T . Q
 //     (STAGES = 1: barrier, DMA tile t+1)
-template <int DP, bool DROP, bool BF, int STAGES>
+template <int DP, bool DROP, int STAGES>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int bx, const int h, const int n) {
     constexpr int TS = 32 * DP, NJ = DP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1017,8 +966,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     issue(0);                                   // first Q/dO tile travels while the register fragment and the lse/delta rows are fetched
 
     float Fr[DP / 2];                           // K fragment (S-wave) or V fragment (D-wave)
-    if (role == 0) load_rowfrag<DP, BF>(Fr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
-    else load_rowfrag<DP, BF>(Fr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    if (role == 0) load_rowfrag<DP>(Fr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
+    else load_rowfrag<DP>(Fr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, a.d, half);
     const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
     const int64_t srow = ((int64_t)n * a.heads + h) * a.Tq;
     for (int j = tid; j < nqt * 32; j += nthr) {
@@ -1046,7 +995,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
         if (active) {
             if (role == 0) {
                 // S[query][key]: rows = queries of the tile (krow order down the registers), column = this lane's key
-                const f32x16 S = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Qs, Fr, lo);
+                const f32x16 S = mma_rows<DP, YT_ATTN_BWD_PIPE>(Qs, Fr, lo);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 ls = lds4(Lrow + i0 + 8 * g + 4 * half);
@@ -1055,7 +1004,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                     *reinterpret_cast<float4*>(Xp + (g * 64 + lane) * 4) = make_float4(W[4 * g], W[4 * g + 1], W[4 * g + 2], W[4 * g + 3]);
                 }
             } else {
-                const f32x16 dP = mma_rows<DP, BF, YT_ATTN_BWD_PIPE>(Gs, Fr, lo);
+                const f32x16 dP = mma_rows<DP, YT_ATTN_BWD_PIPE>(Gs, Fr, lo);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) W[r] = dP[r];
             }
@@ -1068,7 +1017,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                     for (int r = 0; r < 16; ++r)
                         W[r] = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + krow(r, half)), key) >= thr ? W[r] * ik : 0.f;
                 }
-                mma_regs_rows<DP, BF, YT_ATTN_BWD_PIPE>(acc, W, Gs, lo);          // dV += P~^T . dO
+                mma_regs_rows<DP, YT_ATTN_BWD_PIPE>(acc, W, Gs, lo);          // dV += P~^T . dO
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1083,7 +1032,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                         W[r] = pvv[u] * (dp - dsv[u]);
                     }
                 }
-                mma_regs_rows<DP, BF, YT_ATTN_BWD_PIPE>(acc, W, Qs, lo);          // dK += dS^T . Q
+                mma_regs_rows<DP, YT_ATTN_BWD_PIPE>(acc, W, Qs, lo);          // dK += dS^T . Q
             }
         }
         if (STAGES == 1 && t + 1 < nqt) {
@@ -1161,9 +1110,9 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
         constexpr bool more = decltype(MORE_T)::value;
         const int i0 = t * 32;
         w1_wait<DP / 8>();           // Q(t); dO(t) may still be on its way
-        const f32x16 S = mma_rows<DP, false, W1_PIPE>(Qs, Kr, lo);
+        const f32x16 S = mma_rows<DP, W1_PIPE>(Qs, Kr, lo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // dO(t)
-        const f32x16 dP = mma_rows<DP, false, W1_PIPE>(Gs, Vr, lo);
+        const f32x16 dP = mma_rows<DP, W1_PIPE>(Gs, Vr, lo);
         float Pk[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1184,10 +1133,10 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
                 dS[r] = p * (dp - dsv[u]);
             }
         }
-        mma_regs_rows<DP, false, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
+        mma_regs_rows<DP, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
         asm volatile("" ::: "memory");
         if (more) qtile(i0 + 32);
-        mma_regs_rows<DP, false, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
+        mma_regs_rows<DP, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
         asm volatile("" ::: "memory");
         if (more) gtile(i0 + 32);
     };
@@ -1233,18 +1182,18 @@ struct AttnLaunch { AttnArgs p[2]; int nb0, gx0, gx1; };
     const int bx = bid % gx, h = (bid / gx) % a.heads, n = bid / (gx * a.heads);                               \
     BODY_CALL
 
-template <int DP, bool DROP, bool BF>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<DP, DROP, BF>(a, bx, h, n))); }
+template <int DP, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP>
 __global__ __launch_bounds__(64) void attn_fwd_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_fwd_w1_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dq_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_w1_body<DP, DROP>(a, bx, h, n))); }
-template <int DP, bool DROP, bool BF>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_body<DP, DROP, BF>(a, bx, h, n))); }
+template <int DP, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dq_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_w1_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_w1_body<DP, DROP>(a, bx, h, n))); }
-template <int DP, bool DROP, bool BF, int STAGES>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_body<DP, DROP, BF, STAGES>(a, bx, h, n))); }
+template <int DP, bool DROP, int STAGES>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnLaunch b) { YT_ATTN_DECODE((attn_bwd_dkv_body<DP, DROP, STAGES>(a, bx, h, n))); }
 #undef YT_ATTN_DECODE
 
 // Waves per workgroup of the forward / dQ kernels (32 queries each).  d > 64 (256-VGPR kernels, two waves per SIMD, 33 KB of LDS): two-wave
@@ -1261,16 +1210,12 @@ static int pick_waves(int T, int d) {
     return best;
 }
 // Pairs of waves per workgroup of the dK/dV kernel (32 keys per pair) and the number of Q/dO tile stages.
-static int pick_pairs(int T, int d, int bf16) {
+static int pick_pairs(int T, int d) {
     const int tiles = (int)cdiv(T, 32);
     if (tiles == 1) return 1;
-    if (bf16) return 2;          // (the one-stage bf16 instantiation at d = 128 spills 200+ registers: two pairs, two stages)
     return d > 64 ? 1 : 2;
 }
-static int pick_stages(int d, int npairs, int bf16) {
-    if (bf16) return 2;
-    return (d > 64 && npairs == 1) ? 1 : 2;
-}
+static int pick_stages(int d, int npairs) { return (d > 64 && npairs == 1) ? 1 : 2; }
 
 static int check_common(const char* who, const AttnArgs& a) {
     YT_REQUIRE(a.q && a.k && a.v, "%s: null q/k/v", who);
@@ -1292,39 +1237,27 @@ static size_t lds_dkv(int dp, int stages, int npairs, int Tq) {
     return (size_t)(stages * 2 * 32 * dp + npairs * 1024 + 2 * (int)cdiv(Tq, 32) * 32) * sizeof(float);
 }
 
-#define YT_DISPATCH3(KERNEL, DPV, DROPV, BFV, ...) hipLaunchKernelGGL((KERNEL<DPV, DROPV, BFV>), __VA_ARGS__)
-#define YT_DISPATCH_DROP_BF(KERNEL, DPV, drop_, bf_, ...)                              \
+#define YT_DISPATCH_DROP(KERNEL, DPV, drop_, ...)                                      \
     do {                                                                               \
-        if (drop_) {                                                                   \
-            if (bf_) YT_DISPATCH3(KERNEL, DPV, true, true, __VA_ARGS__);               \
-            else YT_DISPATCH3(KERNEL, DPV, true, false, __VA_ARGS__);                  \
-        } else {                                                                       \
-            if (bf_) YT_DISPATCH3(KERNEL, DPV, false, true, __VA_ARGS__);              \
-            else YT_DISPATCH3(KERNEL, DPV, false, false, __VA_ARGS__);                 \
-        }                                                                              \
+        if (drop_) hipLaunchKernelGGL((KERNEL<DPV, true>), __VA_ARGS__);               \
+        else hipLaunchKernelGGL((KERNEL<DPV, false>), __VA_ARGS__);                    \
     } while (0)
-#define YT_DISPATCH(KERNEL, dp_, drop_, bf_, ...)                                      \
+#define YT_DISPATCH(KERNEL, dp_, drop_, ...)                                           \
     do {                                                                               \
-        if ((dp_) == 32) YT_DISPATCH_DROP_BF(KERNEL, 32, drop_, bf_, __VA_ARGS__);     \
-        else if ((dp_) == 64) YT_DISPATCH_DROP_BF(KERNEL, 64, drop_, bf_, __VA_ARGS__);\
-        else YT_DISPATCH_DROP_BF(KERNEL, 128, drop_, bf_, __VA_ARGS__);                \
+        if ((dp_) == 32) YT_DISPATCH_DROP(KERNEL, 32, drop_, __VA_ARGS__);             \
+        else if ((dp_) == 64) YT_DISPATCH_DROP(KERNEL, 64, drop_, __VA_ARGS__);        \
+        else YT_DISPATCH_DROP(KERNEL, 128, drop_, __VA_ARGS__);                        \
     } while (0)
-#define YT_DKV3(ST, DPV, DROPV, BFV, ...) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, DROPV, BFV, ST>), __VA_ARGS__)
-#define YT_DKV_DROP_BF(ST, DPV, drop_, bf_, ...)                                       \
+#define YT_DKV_DROP(ST, DPV, drop_, ...)                                               \
     do {                                                                               \
-        if (drop_) {                                                                   \
-            if (bf_) YT_DKV3(ST, DPV, true, true, __VA_ARGS__);                        \
-            else YT_DKV3(ST, DPV, true, false, __VA_ARGS__);                           \
-        } else {                                                                       \
-            if (bf_) YT_DKV3(ST, DPV, false, true, __VA_ARGS__);                       \
-            else YT_DKV3(ST, DPV, false, false, __VA_ARGS__);                          \
-        }                                                                              \
+        if (drop_) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, true, ST>), __VA_ARGS__);   \
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPV, false, ST>), __VA_ARGS__);        \
     } while (0)
-#define YT_DKV_DP(ST, dp_, drop_, bf_, ...)                                            \
+#define YT_DKV_DP(ST, dp_, drop_, ...)                                                 \
     do {                                                                               \
-        if ((dp_) == 32) YT_DKV_DROP_BF(ST, 32, drop_, bf_, __VA_ARGS__);              \
-        else if ((dp_) == 64) YT_DKV_DROP_BF(ST, 64, drop_, bf_, __VA_ARGS__);         \
-        else YT_DKV_DROP_BF(ST, 128, drop_, bf_, __VA_ARGS__);                         \
+        if ((dp_) == 32) YT_DKV_DROP(ST, 32, drop_, __VA_ARGS__);                      \
+        else if ((dp_) == 64) YT_DKV_DROP(ST, 64, drop_, __VA_ARGS__);                 \
+        else YT_DKV_DROP(ST, 128, drop_, __VA_ARGS__);                                 \
     } while (0)
 
 }  // namespace ytvln
@@ -1345,7 +1278,7 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
     }
     // one wave per workgroup and per SIMD (attn_fwd_w1_body); option ATTN_W1 bit 0 clear: the two-wave form everywhere
     const bool w1_dim = a0.d == 128 || a0.d == 64;             // unpadded heads the one-wave kernels are instantiated for
-    if ((opt(OPT_ATTN_W1) & 1) && w1_dim && !a0.bf16 && maxTk <= 512) {
+    if ((opt(OPT_ATTN_W1) & 1) && w1_dim && maxTk <= 512) {
         b.gx0 = (int)cdiv(b.p[0].Tq, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
@@ -1372,10 +1305,10 @@ static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
     b.nb0 = b.gx0 * a0.heads * a0.N;
     const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
     YT_REQUIRE(total < (1ll << 31), "attn_fwd: grid too large");
-    const bool dsplit = opt(OPT_ATTN_DSPLIT) && dp == 128 && nw == 2 && !a0.bf16;
+    const bool dsplit = opt(OPT_ATTN_DSPLIT) && dp == 128 && nw == 2;
     for (int i = 0; i < np; ++i) b.p[i].dsplit = dsplit;
     const size_t lds_bytes = lds_fwd(dp, maxTk) + (dsplit ? 4096 : 0);
-    YT_DISPATCH(attn_fwd_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_bytes, s, b);
+    YT_DISPATCH(attn_fwd_kernel, dp, drop, dim3((unsigned)total), dim3(64 * nw), lds_bytes, s, b);
     YT_LAUNCH_CHECK("attn_fwd");
     return 0;
 }
@@ -1399,7 +1332,7 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
     for (int i = 0; i < np; ++i) b.p[i].delta_out = const_cast<float*>(b.p[i].delta);
     {
         // one wave per workgroup and per SIMD (attn_bwd_dq_w1_body); option ATTN_W1 bit 1 clear: the two-wave form
-        const bool w1 = (opt(OPT_ATTN_W1) & 2) && (a0.d == 128 || a0.d == 64) && !a0.bf16 && maxTk <= 512;      // (unpadded heads, mask row in registers)
+        const bool w1 = (opt(OPT_ATTN_W1) & 2) && (a0.d == 128 || a0.d == 64) && maxTk <= 512;      // (unpadded heads, mask row in registers)
         const int nw = w1 ? 1 : pick_waves(maxTq, a0.d);
         b.gx0 = (int)cdiv(b.p[0].Tq, 32 * nw);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32 * nw) : 1;
@@ -1407,7 +1340,7 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
         YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
         if (w1) YT_W1(attn_bwd_dq_w1_kernel, lds_fwd(dp, maxTk));
-        else YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
+        else YT_DISPATCH(attn_bwd_dq_kernel, dp, drop, dim3((unsigned)total), dim3(64 * nw), lds_fwd(dp, maxTk), s, b);
     }
     // one wave per workgroup and per SIMD (attn_bwd_dkv_w1_body; option ATTN_W1 bit 2 clear: always the wave-pair form): unpadded fp32 heads, lse /
     // delta rows staged by one wave, and at least two rounds of the 1024 wave slots (a 1.3-round launch -- 3 key tiles x 448 heads -- pays for 2:
@@ -1415,7 +1348,7 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
     const int64_t w1_waves = (cdiv(b.p[0].Tk, 32) + (np > 1 ? cdiv(b.p[1].Tk, 32) : 0)) * a0.heads * a0.N;
     const int64_t w1_slots = a0.d == 128 ? 1024 : 2048;          // (d = 64: 17 KB of LDS and < 256 registers per wave -> two per SIMD)
     const bool w1_fill = w1_waves * 100 >= cdiv(w1_waves, w1_slots) * w1_slots * 85;      // the last round at least ~85 % useful overall
-    if ((opt(OPT_ATTN_W1) & 4) && (a0.d == 128 || a0.d == 64) && !a0.bf16 && maxTq <= 512 && (w1_fill || opt(OPT_ATTN_W1_DKV_ANY))) {
+    if ((opt(OPT_ATTN_W1) & 4) && (a0.d == 128 || a0.d == 64) && maxTq <= 512 && (w1_fill || opt(OPT_ATTN_W1_DKV_ANY))) {
         b.gx0 = (int)cdiv(b.p[0].Tk, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
@@ -1425,58 +1358,29 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
         YT_W1(attn_bwd_dkv_w1_kernel, lds);
 #undef YT_W1
     } else {
-        const int npairs = pick_pairs(maxTk, a0.d, a0.bf16), stages = pick_stages(a0.d, npairs, a0.bf16);
+        const int npairs = pick_pairs(maxTk, a0.d), stages = pick_stages(a0.d, npairs);
         b.gx0 = (int)cdiv(b.p[0].Tk, 32 * npairs);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32 * npairs) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
         const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
         YT_REQUIRE(total < (1ll << 31), "attn_bwd: grid too large");
         const size_t lds = lds_dkv(dp, stages, npairs, maxTq);
-        if (stages == 1) YT_DKV_DP(1, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(128 * npairs), lds, s, b);
-        else YT_DKV_DP(2, dp, drop, a0.bf16 != 0, dim3((unsigned)total), dim3(128 * npairs), lds, s, b);
+        if (stages == 1) YT_DKV_DP(1, dp, drop, dim3((unsigned)total), dim3(128 * npairs), lds, s, b);
+        else YT_DKV_DP(2, dp, drop, dim3((unsigned)total), dim3(128 * npairs), lds, s, b);
     }
     YT_LAUNCH_CHECK("attn_bwd");
     return 0;
 }
 
-static int attn_fwd_impl(int bf16, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                         const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
-                         int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
+extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                  const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
+                                  int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
     AttnLaunch b = {};
     AttnArgs& a = b.p[0];
-    a.bf16 = bf16;
     a.q = q; a.k = k; a.v = v; a.mask = mask; a.out = ctx; a.lse_out = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
     return launch_fwd(b, 1, as_stream(stream));
-}
-
-extern "C" int ytvln_attn_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                  const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
-                                  int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
-    return attn_fwd_impl(0, q, ldq, k, ldk, v, ldv, mask, ctx, ldo, lse, N, heads, Tq, Tk, d, scale, p_drop, rng, site, stream);
-}
-
-extern "C" int ytvln_attn_fwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                   const float* mask, float* ctx, int64_t ldo, float* lse, int N, int heads, int Tq, int Tk,
-                                   int d, float scale, float p_drop, const int64_t* rng, int64_t site, void* stream) {
-    YT_REQUIRE(d % 8 == 0, "attn_fwd_bf16: head dim %d must be a multiple of 8", d);
-    return attn_fwd_impl(1, q, ldq, k, ldk, v, ldv, mask, ctx, ldo, lse, N, heads, Tq, Tk, d, scale, p_drop, rng, site, stream);
-}
-
-static int attn_bwd_impl(int bf16, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                         const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
-                         float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
-                         int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
-                         int64_t site, void* stream) {
-    AttnLaunch b = {};
-    AttnArgs& a = b.p[0];
-    a.bf16 = bf16;
-    a.q = q; a.k = k; a.v = v; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta;
-    a.dq = dq; a.dk = dk; a.dv = dv;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-    a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
-    return launch_bwd(b, 1, as_stream(stream));
 }
 
 extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
@@ -1484,48 +1388,40 @@ extern "C" int ytvln_attn_bwd_f32(const float* q, int64_t ldq, const float* k, i
                                   float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
                                   int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
                                   int64_t site, void* stream) {
-    return attn_bwd_impl(0, q, ldq, k, ldk, v, ldv, mask, ctx, dctx, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, N, heads, Tq, Tk, d,
-                         scale, p_drop, rng, site, stream);
-}
-
-extern "C" int ytvln_attn_bwd_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                   const float* mask, const float* ctx, const float* dctx, int64_t ldo, const float* lse,
-                                   float* delta, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
-                                   int N, int heads, int Tq, int Tk, int d, float scale, float p_drop, const int64_t* rng,
-                                   int64_t site, void* stream) {
-    YT_REQUIRE(d % 8 == 0, "attn_bwd_bf16: head dim %d must be a multiple of 8", d);
-    return attn_bwd_impl(1, q, ldq, k, ldk, v, ldv, mask, ctx, dctx, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, N, heads, Tq, Tk, d,
-                         scale, p_drop, rng, site, stream);
+    AttnLaunch b = {};
+    AttnArgs& a = b.p[0];
+    a.q = q; a.k = k; a.v = v; a.mask = mask; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta;
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.N = N; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.d = d; a.scale = scale; a.p_drop = p_drop; a.rng = rng; a.site = site;
+    return launch_bwd(b, 1, as_stream(stream));
 }
 
 // ---- both directions of BertBiAttention in one launch -----------------------------------------------------------------------
-static void fill_args(AttnArgs& a, const ytvln_attn_problem& pr, int N, int heads, int d, float scale, const int64_t* rng, int bf16) {
+static void fill_args(AttnArgs& a, const ytvln_attn_problem& pr, int N, int heads, int d, float scale, const int64_t* rng) {
     a = AttnArgs{};
     a.q = pr.q; a.k = pr.k; a.v = pr.v; a.mask = pr.mask;
     a.ctx = pr.ctx_in; a.dctx = pr.dctx; a.lse = pr.lse_in; a.delta = pr.delta;
     a.out = pr.ctx; a.lse_out = pr.lse; a.dq = pr.dq; a.dk = pr.dk; a.dv = pr.dv;
     a.ldq = pr.ldq; a.ldk = pr.ldk; a.ldv = pr.ldv; a.ldo = pr.ldo; a.lddq = pr.lddq; a.lddk = pr.lddk; a.lddv = pr.lddv;
     a.N = N; a.heads = heads; a.Tq = pr.Tq; a.Tk = pr.Tk; a.d = d; a.scale = scale; a.p_drop = pr.p_drop; a.rng = rng; a.site = pr.site;
-    a.bf16 = bf16;
 }
 
 extern "C" int ytvln_attn_fwd_pair(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,
-                                   const int64_t* rng, int bf16, void* stream) {
+                                   const int64_t* rng, void* stream) {
     YT_REQUIRE(pa && pb, "attn_fwd_pair: null problem");
-    const int bf = (bf16 && d % 8 == 0) ? 1 : 0;
     AttnLaunch b = {};
-    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf);
-    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf);
+    fill_args(b.p[0], *pa, N, heads, d, scale, rng);
+    fill_args(b.p[1], *pb, N, heads, d, scale, rng);
     return launch_fwd(b, 2, as_stream(stream));
 }
 
 extern "C" int ytvln_attn_bwd_pair(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,
-                                   const int64_t* rng, int bf16, void* stream) {
+                                   const int64_t* rng, void* stream) {
     YT_REQUIRE(pa && pb, "attn_bwd_pair: null problem");
-    const int bf = (bf16 && d % 8 == 0) ? 1 : 0;
     AttnLaunch b = {};
-    fill_args(b.p[0], *pa, N, heads, d, scale, rng, bf);
-    fill_args(b.p[1], *pb, N, heads, d, scale, rng, bf);
+    fill_args(b.p[0], *pa, N, heads, d, scale, rng);
+    fill_args(b.p[1], *pb, N, heads, d, scale, rng);
     return launch_bwd(b, 2, as_stream(stream));
 }
 

@@ -695,40 +695,6 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
 
 static int plan_splits(int M, int N, int K, int epilogue) { return plan_gemm(M, N, K, epilogue).splits; }
 
-// bf16 launches (K counted in 4-byte words): matrix time is 8x shorter, so the legacy occupancy rule (fill whole rounds of the 512
-// resident workgroups, at least 8 k-tiles per split) is kept for them.
-static int plan_splits_bf16(int M, int N, int K, int epilogue) {
-    if (epilogue != YTVLN_EPI_NONE) return 1;
-    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
-    if (tiles >= 384 || K < 1024) return 1;
-    const int smax = (int)std::min<int64_t>(64, K / 256);
-    int best = 1;
-    double best_eff = (double)tiles / (double)(cdiv(tiles, 512) * 512);
-    for (int sp = 2; sp <= smax; ++sp) {
-        const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
-        const int64_t blocks = tiles * cdiv(K, kchunk);
-        const double eff = (double)blocks / (double)(cdiv(blocks, 512) * 512);
-        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
-    }
-    return best;
-}
-
-// Round 2: with few output tiles and a long contraction (the bf16 weight gradients: K = all rows of the batch) the 256x256 tile with split-K
-// beats 128x128 with split-K -- half the operand bytes per flop, and the bf16 kernels are bound by operand delivery, not by the matrix
-// pipe.  Taken when tiles256 x splits fills most of ONE round of the 256 CUs with at least 8 k-tiles per split; YTVLN_BF16_BIG_SPLIT=0
-// restores the 128x128 rule.  K in 4-byte words.
-static int plan_splits_bf16_any(int M, int N, int K, int epilogue, bool* big) {
-    static const int on = getenv("YTVLN_BF16_BIG_SPLIT") ? atoi(getenv("YTVLN_BF16_BIG_SPLIT")) : 1;
-    *big = false;
-    const int base = plan_splits_bf16(M, N, K, epilogue);
-    if (!on || epilogue != YTVLN_EPI_NONE || M < 256 || N < 256 || base < 2) return base;
-    const int64_t t256 = cdiv(M, 256) * cdiv(N, 256);
-    if (t256 >= 200) return base;
-    const int sp = (int)std::min<int64_t>(256 / t256, K / 256);
-    if (sp >= 2 && t256 * sp >= 200) { *big = true; return sp; }
-    return base;
-}
-
 template <int BM, int BN>
 static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
     g.tiles_m = (int)cdiv(g.M, BM);
@@ -776,152 +742,6 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
 }
 
 
-// ---- bf16 operand staging ---------------------------------------------------------------------------------------------------
-// out[r][c] = bf16(x[r][c]) for c < cols, 0 for cols <= c < ldo  (round to nearest even; ldo = cols rounded up to 64 so the GEMM's
-// 64-deep k-tiles never read past the row).  One thread converts 8 consecutive columns (two 16-byte loads -> one 16-byte store).
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ uint32_t bf16_pack(float lo, float hi) { return bf16_rne(lo) | (bf16_rne(hi) << 16); }
-
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, uint16_t* __restrict__ out,
-                                                        int64_t ldo, int vec) {
-    const int g8 = (int)(ldo >> 3);
-    const int64_t total = (int64_t)rows * g8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / g8), c = (int)(i % g8) << 3;
-        const float* p = x + (int64_t)r * ldx + c;
-        float v[8];
-        if (vec && c + 8 <= cols) {
-            const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = c + u < cols ? p[u] : 0.f;
-        }
-        uint4 o = make_uint4(bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3]), bf16_pack(v[4], v[5]), bf16_pack(v[6], v[7]));
-        *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + c) = o;
-    }
-}
-
-// out[c][r] = bf16(x[r][c]) for r < rows, 0 for rows <= r < ldo: the transposing variant for operands whose contraction index
-// is the ROW of the fp32 matrix (dY^T, X^T of the weight-gradient GEMM; W^T of the input-gradient GEMM).  64 x 64 tiles through
-// LDS: coalesced 16-byte loads along c, 16-byte stores of 8 consecutive r.
-__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols, uint16_t* __restrict__ out,
-                                                          int64_t ldo, int vec) {
-    __shared__ float tile[64][65];
-    const int tiles_c = (cols + 63) >> 6;
-    const int r0 = (blockIdx.x / tiles_c) << 6, c0 = (blockIdx.x % tiles_c) << 6;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {                       // 64 rows x 16 float4
-        const int idx = tid + 256 * it, r = idx >> 4, c = (idx & 15) << 2;
-        const int gr = r0 + r, gc = c0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < rows) {
-            const float* p = x + (int64_t)gr * ldx + gc;
-            if (vec && gc + 4 <= cols) v = *reinterpret_cast<const float4*>(p);
-            else {
-                if (gc < cols) v.x = p[0];
-                if (gc + 1 < cols) v.y = p[1];
-                if (gc + 2 < cols) v.z = p[2];
-                if (gc + 3 < cols) v.w = p[3];
-            }
-        }
-        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {                       // 64 output rows (c) x 8 groups of 8 r
-        const int idx = tid + 256 * it, c = idx >> 3, r = (idx & 7) << 3;
-        if (c0 + c < cols && r0 + r < ldo) {
-            uint4 o = make_uint4(bf16_pack(tile[r][c], tile[r + 1][c]), bf16_pack(tile[r + 2][c], tile[r + 3][c]),
-                                 bf16_pack(tile[r + 4][c], tile[r + 5][c]), bf16_pack(tile[r + 6][c], tile[r + 7][c]));
-            *reinterpret_cast<uint4*>(out + (int64_t)(c0 + c) * ldo + r0 + r) = o;
-        }
-    }
-}
-
-// Both stagings of one fp32 matrix in a single pass (a gradient dY feeds the input-gradient GEMM as [rows][cols] and the
-// weight-gradient GEMM as [cols][rows]): x is read once, 64 x 64 tiles through LDS as in cast_bf16_t_kernel.
-// COLSUM: the block also leaves the column sums of its 64 rows in part[blockRow][c] (fixed summation order: 16-row quarters, then the
-// four quarters) -- the first stage of the bias gradient db = colsum(dY), riding on the pass that reads dY anyway.
-template <bool COLSUM>
-__global__ __launch_bounds__(256) void cast_bf16_dual_kernel(const float* __restrict__ x, int64_t ldx, int rows, int cols,
-                                                             uint16_t* __restrict__ outp, int64_t ldp, uint16_t* __restrict__ outt, int64_t ldt,
-                                                             int vec, float* __restrict__ part) {
-    __shared__ float tile[64][65];
-    const int tiles_c = (int)(ldp >> 6);
-    const int r0 = (blockIdx.x / tiles_c) << 6, c0 = (blockIdx.x % tiles_c) << 6;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {                       // 64 rows x 16 float4
-        const int idx = tid + 256 * it, r = idx >> 4, c = (idx & 15) << 2;
-        const int gr = r0 + r, gc = c0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < rows) {
-            const float* p = x + (int64_t)gr * ldx + gc;
-            if (vec && gc + 4 <= cols) v = *reinterpret_cast<const float4*>(p);
-            else {
-                if (gc < cols) v.x = p[0];
-                if (gc + 1 < cols) v.y = p[1];
-                if (gc + 2 < cols) v.z = p[2];
-                if (gc + 3 < cols) v.w = p[3];
-            }
-            // plain staging straight from the registers (zero tail up to ldp comes with the zero-filled v)
-            *reinterpret_cast<uint2*>(outp + (int64_t)gr * ldp + gc) = make_uint2(bf16_pack(v.x, v.y), bf16_pack(v.z, v.w));
-        }
-        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {                       // 64 output rows (c) x 8 groups of 8 r
-        const int idx = tid + 256 * it, c = idx >> 3, r = (idx & 7) << 3;
-        if (c0 + c < cols && r0 + r < ldt) {
-            uint4 o = make_uint4(bf16_pack(tile[r][c], tile[r + 1][c]), bf16_pack(tile[r + 2][c], tile[r + 3][c]),
-                                 bf16_pack(tile[r + 4][c], tile[r + 5][c]), bf16_pack(tile[r + 6][c], tile[r + 7][c]));
-            *reinterpret_cast<uint4*>(outt + (int64_t)(c0 + c) * ldt + r0 + r) = o;
-        }
-    }
-    if constexpr (COLSUM) {
-        __shared__ float quarter[4][64];
-        const int c = tid & 63, q = tid >> 6;
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc += tile[16 * q + r][c];          // rows past `rows` were staged as zeros
-        quarter[q][c] = acc;
-        __syncthreads();
-        if (tid < 64 && c0 + tid < cols)
-            part[(int64_t)(blockIdx.x / tiles_c) * cols + c0 + tid] = (quarter[0][tid] + quarter[1][tid]) + (quarter[2][tid] + quarter[3][tid]);
-    }
-}
-
-// bf16 tiles.  With 8x shorter matrix time the operand path (LDS-DMA issue, ~1 KiB per wave instruction) is what a workgroup waits
-// for, so the 256x256 tile (half the operand bytes per flop, one workgroup per CU) wins wherever it fills the chip about as well as
-// 128x128 does: +15-19 % on 129024x1024x1024 / 16128x3072x1024, +10 % on 4480x3072x768, level on 16128x1024x1024 (measured,
-// kernel alone).  Split-K launches and fused activations (their epilogue is exposed with one workgroup per CU) stay on 128x128.
-static bool bf16_big_tile(const GemmArgs& g) {
-    static const int force = getenv("YTVLN_BF16_TILE") ? atoi(getenv("YTVLN_BF16_TILE")) : -1;      // experiment knob: 0 / 4
-    if (force == 0 || force == 4) return force == 4 && g.M >= 256 && g.N >= 256;
-    if (g.splits > 1 || (g.epilogue != YTVLN_EPI_NONE && force != 5) || g.M < 256 || g.N < 256) return false;
-    const double b128 = (double)(cdiv(g.M, 128) * cdiv(g.N, 128)), b256 = (double)(cdiv(g.M, 256) * cdiv(g.N, 256));
-    const double e128 = b128 / (ceil(b128 / 512.0) * 512.0), e256 = b256 / (ceil(b256 / 256.0) * 256.0);
-    return b256 >= 200.0 && e256 >= e128 - 0.05;
-}
-
-static void launch_bf16(GemmArgs& g, hipStream_t s, bool big_split = false) {
-    const bool big = big_split || bf16_big_tile(g);
-    const int bt = big ? 256 : 128;
-    g.tiles_m = (int)cdiv(g.M, bt);
-    g.tiles_n = (int)cdiv(g.N, bt);
-    g.ntiles = g.tiles_m * g.tiles_n;
-    const dim3 grid(g.ntiles * g.splits);
-    if (big) hipLaunchKernelGGL((gemm_dma_kernel<256, 256, true, true, 8, 32, 2, 2, true>), grid, dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, true, true, 8, 32, 2, 4, true>), grid, dim3(512), 0, s, g);
-}
-
 }  // namespace ytvln
 
 using namespace ytvln;
@@ -944,12 +764,11 @@ extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue,
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
-    bool big_unused = false;
     const int splits = std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, true).splits),
                                          std::max(plan_gemm(M, N, K, epilogue, false, true).splits,
                                                   plan_gemm(M, N, K, epilogue, true, true).splits)),
-                                std::max(plan_splits_bf16(M, N, K, epilogue), plan_splits_bf16_any(M, N, K, epilogue, &big_unused)));
-    // (covers both GEMM entry points, either A layout, the fp32x3 plans and both bf16 split rules)
+                                1);
+    // (covers either A layout and the fp32x3 plans)
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
     return need;
 }
@@ -1047,92 +866,4 @@ extern "C" int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, co
                          a_rowsum, rowsum_done, stream);
 }
 
-extern "C" int ytvln_cast_bf16(const float* x, int64_t ldx, int rows, int cols, int transpose, uint16_t* out, int64_t ldo, void* stream) {
-    YT_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols, "cast_bf16: bad argument");
-    const int contract = transpose ? rows : cols;
-    YT_REQUIRE(ldo % 64 == 0 && ldo >= contract && ldo < contract + 64, "cast_bf16: ldo must be the contraction length rounded up to 64");
-    YT_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "cast_bf16: output must be 16-byte aligned");
-    const int vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
-    hipStream_t s = as_stream(stream);
-    if (!transpose) {
-        const int64_t total = (int64_t)rows * (ldo >> 3);
-        hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, s, x, ldx, rows, cols, out, ldo, vec);
-    } else {
-        const int64_t tiles = cdiv(ldo, 64) * cdiv(cols, 64);
-        YT_REQUIRE(tiles < (1ll << 31), "cast_bf16: matrix too large");
-        hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, rows, cols, out, ldo, vec);
-    }
-    YT_LAUNCH_CHECK("cast_bf16");
-    return 0;
-}
-
-static int cast_bf16_dual_impl(const char* name, const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
-                               uint16_t* out_t, int64_t ld_t, float* colsum_part, void* stream) {
-    YT_REQUIRE(x && out_plain && out_t && rows > 0 && cols > 0 && ldx >= cols, "%s: bad argument", name);
-    YT_REQUIRE(ld_plain % 64 == 0 && ld_plain >= cols && ld_plain < cols + 64 && ld_t % 64 == 0 && ld_t >= rows && ld_t < rows + 64,
-               "%s: leading dimensions must be the contraction lengths rounded up to 64", name);
-    YT_REQUIRE(((reinterpret_cast<uintptr_t>(out_plain) | reinterpret_cast<uintptr_t>(out_t)) & 15) == 0, "%s: outputs must be 16-byte aligned", name);
-    const int vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
-    const int64_t tiles = (ld_t / 64) * (ld_plain / 64);
-    YT_REQUIRE(tiles < (1ll << 31), "%s: matrix too large", name);
-    if (colsum_part)
-        hipLaunchKernelGGL(cast_bf16_dual_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, out_plain,
-                           ld_plain, out_t, ld_t, vec, colsum_part);
-    else
-        hipLaunchKernelGGL(cast_bf16_dual_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), x, ldx, rows, cols, out_plain,
-                           ld_plain, out_t, ld_t, vec, (float*)nullptr);
-    YT_LAUNCH_CHECK(name);
-    return 0;
-}
-
-extern "C" int ytvln_cast_bf16_dual(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
-                                    uint16_t* out_t, int64_t ld_t, void* stream) {
-    return cast_bf16_dual_impl("cast_bf16_dual", x, ldx, rows, cols, out_plain, ld_plain, out_t, ld_t, nullptr, stream);
-}
-
-// Same staging, plus colsum_part[b][c] = sum of x[r][c] over the 64 rows r of row block b (b < ceil(rows / 64), c < cols): the first stage
-// of a deterministic column sum (finish with ytvln_colsum_f32 over the [ceil(rows/64)][cols] partials).
-extern "C" int ytvln_cast_bf16_dual_colsum(const float* x, int64_t ldx, int rows, int cols, uint16_t* out_plain, int64_t ld_plain,
-                                           uint16_t* out_t, int64_t ld_t, float* colsum_part, void* stream) {
-    YT_REQUIRE(colsum_part != nullptr, "cast_bf16_dual_colsum: NULL partial buffer");
-    return cast_bf16_dual_impl("cast_bf16_dual_colsum", x, ldx, rows, cols, out_plain, ld_plain, out_t, ld_t, colsum_part, stream);
-}
-
-extern "C" int ytvln_gemm_bf16_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
-                                  float* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta, float* workspace,
-                                  int64_t workspace_elems, void* stream) {
-    YT_REQUIRE(A && B && C, "gemm_bf16: null operand");
-    YT_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_bf16: K must be a positive multiple of 64 (stage operands with ytvln_cast_bf16)");
-    YT_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N, "gemm_bf16: bad leading dimension");
-    YT_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0, "gemm_bf16: operands must be 16-byte aligned");
-    YT_REQUIRE(epilogue >= YTVLN_EPI_NONE && epilogue <= YTVLN_EPI_MUL_DRELU, "gemm_bf16: bad epilogue %d", epilogue);
-    YT_REQUIRE(!(epilogue >= YTVLN_EPI_MUL_DGELU) || aux, "gemm_bf16: epilogue %d needs aux", epilogue);
-    GemmArgs g;
-    // the kernel sees the bf16 matrices as float matrices of half the width
-    g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias = bias; g.aux = aux;
-    g.lda = lda / 2; g.ldb = ldb / 2; g.ldc = ldc; g.ldaux = ldaux;
-    g.M = M; g.N = N; g.K = K / 2; g.epilogue = epilogue; g.beta = beta;
-    g.vecA = g.vecB = 1; g.fast = 1; g.Kloop = K / 2; g.ktail = 0; g.mnA = M; g.mnB = N; g.x3 = 0;
-    g.asum = nullptr; g.asum_ws = nullptr; g.split_map = 1;
-    g.splits = 1; g.kchunk = g.Kloop; g.ws = nullptr;
-    bool big_split = false;
-    int want = plan_splits_bf16_any(M, N, K / 2, epilogue, &big_split);
-    if (want > 1 && !(workspace && workspace_elems >= (int64_t)want * M * N)) { big_split = false; want = plan_splits_bf16(M, N, K / 2, epilogue); }
-    if (want > 1 && workspace && workspace_elems >= (int64_t)want * M * N) {
-        g.kchunk = (int)cdiv(cdiv(g.Kloop, want), BK) * BK;
-        g.splits = (int)cdiv(g.Kloop, g.kchunk);
-        g.ws = workspace;
-    } else {
-        big_split = false;
-    }
-    hipStream_t s = as_stream(stream);
-    launch_bf16(g, s, big_split);
-    if (g.splits > 1) {
-        const int64_t total = (int64_t)M * N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
-                           ldc, bias, M, N, g.splits, beta, (const float*)nullptr, (float*)nullptr);
-    }
-    YT_LAUNCH_CHECK("gemm_bf16_nt");
-    return 0;
-}
 #endif  // YT_GEMM_X3_TU

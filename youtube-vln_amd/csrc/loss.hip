@@ -70,19 +70,27 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
     if (threadIdx.x == 0) { out[0] = S / C; out[1] = C; }
 }
 
+// DT = float: the fp32 gradient (columns [0, V)).  DT = uint16_t: the bf16-resident path -- the gradient rounded to bf16 (RNE) AND zeros in the
+// padding columns [V, ldd), so that the buffer can feed the bf16 GEMMs as a zero-padded operand (YTVLN_GEMM_A_ZERO_PADDED) as it stands.
+__device__ __forceinline__ void grad_store(float* d, int c, float v) { d[c] = v; }
+__device__ __forceinline__ void grad_store(uint16_t* d, int c, float v) { d[c] = __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+template <typename DT>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
                                                      int64_t ignore, const float* __restrict__ row_lse, const float* __restrict__ out,
-                                                     const float* __restrict__ gout, float* __restrict__ dl, int64_t ldd, int V) {
+                                                     const float* __restrict__ gout, DT* __restrict__ dl, int64_t ldd, int V) {
     const int row = blockIdx.x;
     const int64_t t = target[row];
-    float* d = dl + (int64_t)row * ldd;
+    DT* d = dl + (int64_t)row * ldd;
+    const int Vz = sizeof(DT) == 2 ? (int)ldd : V;          // bf16: the padding is zeroed too
     if (t == ignore) {
-        for (int c = threadIdx.x; c < V; c += 256) d[c] = 0.f;
+        for (int c = threadIdx.x; c < Vz; c += 256) grad_store(d, c, 0.f);
         return;
     }
     const float coef = gout[0] / out[1], lse = row_lse[row];
     const float* x = logits + (int64_t)row * ld;
-    for (int c = threadIdx.x; c < V; c += 256) d[c] = (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * coef;
+    for (int c = threadIdx.x; c < V; c += 256) grad_store(d, c, (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * coef);
+    for (int c = V + threadIdx.x; c < Vz; c += 256) grad_store(d, c, 0.f);
 }
 
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ pred, int64_t ld, const float* __restrict__ tgt, int64_t ldt,
@@ -117,15 +125,17 @@ __global__ __launch_bounds__(256) void kl_finalize_kernel(const float* __restric
     if (threadIdx.x == 0) { out[0] = S / Cn; out[1] = Cn; }
 }
 
+template <typename DT>
 __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ pred, int64_t ld, const float* __restrict__ tgt, int64_t ldt,
                                                      const int64_t* __restrict__ mask, const float* __restrict__ row_lse,
                                                      const float* __restrict__ out, const float* __restrict__ gout,
-                                                     float* __restrict__ dp, int64_t ldd, int C) {
+                                                     DT* __restrict__ dp, int64_t ldd, int C) {
     __shared__ float sh[4];
     const int row = blockIdx.x;
-    float* d = dp + (int64_t)row * ldd;
+    DT* d = dp + (int64_t)row * ldd;
+    const int Cz = sizeof(DT) == 2 ? (int)ldd : C;
     if (mask[row] == 0) {
-        for (int c = threadIdx.x; c < C; c += 256) d[c] = 0.f;
+        for (int c = threadIdx.x; c < Cz; c += 256) grad_store(d, c, 0.f);
         return;
     }
     const float* x = pred + (int64_t)row * ld;
@@ -134,7 +144,8 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ p
     for (int c = threadIdx.x; c < C; c += 256) ts += t[c];
     const float tsum = block_sum(ts, sh);
     const float coef = gout[0] / out[1] * (float)mask[row], lse = row_lse[row];
-    for (int c = threadIdx.x; c < C; c += 256) d[c] = coef * (expf(x[c] - lse) * tsum - t[c]);
+    for (int c = threadIdx.x; c < C; c += 256) grad_store(d, c, coef * (expf(x[c] - lse) * tsum - t[c]));
+    for (int c = C + threadIdx.x; c < Cz; c += 256) grad_store(d, c, 0.f);
 }
 
 __device__ __forceinline__ float softplus_neg(float x) { return log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f); }   // log(1+exp(-x))
@@ -179,9 +190,18 @@ extern "C" int ytvln_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* 
 extern "C" int ytvln_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
                                 const float* out, const float* gout, float* dlogits, int64_t ldd, int M, int V, void* stream) {
     YT_REQUIRE(logits && target && row_lse && out && gout && dlogits && M > 0 && V > 0 && ldd >= V, "ce_bwd: bad argument");
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), logits, ld, target, ignore_index, row_lse, out, gout,
+    hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(M), dim3(256), 0, as_stream(stream), logits, ld, target, ignore_index, row_lse, out, gout,
                        dlogits, ldd, V);
     YT_LAUNCH_CHECK("ce_bwd");
+    return 0;
+}
+
+extern "C" int ytvln_ce_bwd_bf16(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
+                                 const float* out, const float* gout, uint16_t* dlogits, int64_t ldd, int M, int V, void* stream) {
+    YT_REQUIRE(logits && target && row_lse && out && gout && dlogits && M > 0 && V > 0 && ldd >= V, "ce_bwd_bf16: bad argument");
+    hipLaunchKernelGGL(ce_bwd_kernel<uint16_t>, dim3(M), dim3(256), 0, as_stream(stream), logits, ld, target, ignore_index, row_lse, out, gout,
+                       dlogits, ldd, V);
+    YT_LAUNCH_CHECK("ce_bwd_bf16");
     return 0;
 }
 
@@ -199,9 +219,18 @@ extern "C" int ytvln_kl_bwd_f32(const float* pred, int64_t ld, const float* targ
                                 const float* row_lse, const float* out, const float* gout, float* dpred, int64_t ldd, int M, int C,
                                 void* stream) {
     YT_REQUIRE(pred && target && mask && row_lse && out && gout && dpred && M > 0 && C > 0, "kl_bwd: bad argument");
-    hipLaunchKernelGGL(kl_bwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), pred, ld, target, ldt, mask, row_lse, out, gout, dpred,
+    hipLaunchKernelGGL(kl_bwd_kernel<float>, dim3(M), dim3(256), 0, as_stream(stream), pred, ld, target, ldt, mask, row_lse, out, gout, dpred,
                        ldd, C);
     YT_LAUNCH_CHECK("kl_bwd");
+    return 0;
+}
+
+extern "C" int ytvln_kl_bwd_bf16(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, const float* row_lse,
+                                 const float* out, const float* gout, uint16_t* dpred, int64_t ldd, int M, int C, void* stream) {
+    YT_REQUIRE(pred && target && mask && row_lse && out && gout && dpred && M > 0 && C > 0 && ldd >= C, "kl_bwd_bf16: bad argument");
+    hipLaunchKernelGGL(kl_bwd_kernel<uint16_t>, dim3(M), dim3(256), 0, as_stream(stream), pred, ld, target, ldt, mask, row_lse, out, gout, dpred,
+                       ldd, C);
+    YT_LAUNCH_CHECK("kl_bwd_bf16");
     return 0;
 }
 

@@ -13,16 +13,30 @@ enum { LN_PLAIN = 0, LN_TEXT = 1, LN_IMAGE = 2 };
 
 struct LnArgs {
     // plain
-    const float* x; const float* res;
+    const void* x; const void* res;          // element type XT of the kernel (float, or bf16 for the bf16-resident path)
     // text embedding
     const int64_t* ids; const int64_t* type_ids; const float* word; const float* pos; const float* type; int T;
     // image embedding
     const float* loc; const float* W5; const float* b5; const float* W4; const float* b4; const float* W2;
     const float* b2; const float* E;
     // common
-    const float* gamma; const float* beta; float* y; float* s_out; float* mean; float* rstd;
+    const float* gamma; const float* beta; void* y; void* s_out; float* mean; float* rstd;          // y / s_out: element type YT
     int64_t rows; int H; float eps; float p_pre, p_post; const int64_t* rng; int64_t site;
 };
+
+// Four consecutive elements of a row as fp32: one 16-byte access for float rows, one 8-byte access for bf16 rows (round to nearest even on
+// the way out).  `c4` counts groups of four elements, so the dropout bits (one Philox draw per group) are the same in both precisions.
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float4 ld4(const float* p, int64_t c4) { return reinterpret_cast<const float4*>(p)[c4]; }
+__device__ __forceinline__ float4 ld4(const bf16_t* p, int64_t c4) {
+    const uint2 u = reinterpret_cast<const uint2*>(p)[c4];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, int64_t c4, float4 v) { reinterpret_cast<float4*>(p)[c4] = v; }
+__device__ __forceinline__ uint32_t bfbits(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ void st4(bf16_t* p, int64_t c4, float4 v) {
+    reinterpret_cast<uint2*>(p)[c4] = make_uint2(bfbits(v.x) | (bfbits(v.y) << 16), bfbits(v.z) | (bfbits(v.w) << 16));
+}
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4scale_keep(float4 v, u32x4 b, uint32_t thr, float ik) {
@@ -30,8 +44,12 @@ __device__ __forceinline__ float4 f4scale_keep(float4 v, u32x4 b, uint32_t thr, 
                        b.w >= thr ? v.w * ik : 0.f);
 }
 
-template <int NV, int MODE>
+template <int NV, int MODE, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
+    const XT* const xin = reinterpret_cast<const XT*>(a.x);
+    const XT* const rin = reinterpret_cast<const XT*>(a.res);
+    YT* const yout = reinterpret_cast<YT*>(a.y);
+    YT* const sout = reinterpret_cast<YT*>(a.s_out);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H4 = a.H >> 2;
     const float invH = 1.0f / (float)a.H;
@@ -67,9 +85,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c4 < H4) {
                 if (MODE == LN_PLAIN) {
-                    v = reinterpret_cast<const float4*>(a.x + row * a.H)[c4];
+                    v = ld4(xin + row * a.H, c4);
                     if (pre) v = f4scale_keep(v, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre);
-                    if (a.res) v = f4add(v, reinterpret_cast<const float4*>(a.res + row * a.H)[c4]);
+                    if (rin) v = f4add(v, ld4(rin + row * a.H, c4));
                 } else if (MODE == LN_TEXT) {
                     v = f4add(f4add(reinterpret_cast<const float4*>(wrow)[c4], reinterpret_cast<const float4*>(prow)[c4]),
                               reinterpret_cast<const float4*>(trow)[c4]);
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
                         for (int q = 0; q < 2; ++q) cv = fmaf(w2[q], loc[9 + q], cv);
                         o[u] = ((av + bv) + cv) + erow[c + u];   // a + b + c + d, vilbert.py:1365
                     }
-                    v = f4add(reinterpret_cast<const float4*>(a.x + row * a.H)[c4], make_float4(o[0], o[1], o[2], o[3]));
+                    v = f4add(ld4(xin + row * a.H, c4), make_float4(o[0], o[1], o[2], o[3]));
                 }
                 sum += (v.x + v.y) + (v.z + v.w);
             }
@@ -115,26 +133,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
         for (int j = 0; j < NV; ++j) {
             const int c4 = lane + 64 * j;
             if (c4 < H4) {
-                if (a.s_out) reinterpret_cast<float4*>(a.s_out + row * a.H)[c4] = s[j];
+                if (sout) st4(sout + row * a.H, c4, s[j]);
                 const float4 g = reinterpret_cast<const float4*>(a.gamma)[c4], b = reinterpret_cast<const float4*>(a.beta)[c4];
                 float4 o = make_float4(g.x * ((s[j].x - mu) / sd) + b.x, g.y * ((s[j].y - mu) / sd) + b.y,
                                        g.z * ((s[j].z - mu) / sd) + b.z, g.w * ((s[j].w - mu) / sd) + b.w);
                 if (post) o = f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_post, ik_post);
-                reinterpret_cast<float4*>(a.y + row * a.H)[c4] = o;
+                st4(yout + row * a.H, c4, o);
             }
         }
     }
 }
 
 struct LnBwdArgs {
-    const float* dy; const float* s; const float* mean; const float* rstd; const float* gamma;
-    float* ds; float* dx; float* partial;
+    const void* dy; const void* s; const float* mean; const float* rstd; const float* gamma;      // dy / s: element type XT
+    void* ds; void* dx; float* ds_f32; float* partial;                                               // ds / dx: XT; ds_f32: optional fp32 copy of ds
     int64_t rows; int H; int rows_per_block; float p_pre, p_post; const int64_t* rng; int64_t site;
 };
 
-template <int NV>
+template <int NV, typename XT = float>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2][H]
+    const XT* const dyin = reinterpret_cast<const XT*>(a.dy);
+    const XT* const sin = reinterpret_cast<const XT*>(a.s);
+    XT* const dsout = reinterpret_cast<XT*>(a.ds);
+    XT* const dxout = reinterpret_cast<XT*>(a.dx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H4 = a.H >> 2;
     const float invH = 1.0f / (float)a.H;
@@ -164,9 +186,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             const int c4 = lane + 64 * j;
             g[j] = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = g[j];
             if (c4 < H4) {
-                float4 d = reinterpret_cast<const float4*>(a.dy + row * a.H)[c4];
+                float4 d = ld4(dyin + row * a.H, c4);
                 if (post) d = f4scale_keep(d, drop_bits(key, (uint64_t)row * H4 + c4), thr_post, ik_post);
-                const float4 sv = reinterpret_cast<const float4*>(a.s + row * a.H)[c4];
+                const float4 sv = ld4(sin + row * a.H, c4);
                 xh[j] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
                 dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
                 db[j] = f4add(db[j], d);
@@ -183,10 +205,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             if (c4 < H4) {
                 float4 o = make_float4(rs * (g[j].x - c1 - xh[j].x * c2), rs * (g[j].y - c1 - xh[j].y * c2),
                                        rs * (g[j].z - c1 - xh[j].z * c2), rs * (g[j].w - c1 - xh[j].w * c2));
-                reinterpret_cast<float4*>(a.ds + row * a.H)[c4] = o;
-                if (pre && a.dx)
-                    reinterpret_cast<float4*>(a.dx + row * a.H)[c4] =
-                        f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre);
+                if (dsout) st4(dsout + row * a.H, c4, o);
+                if (a.ds_f32) st4(a.ds_f32 + row * a.H, c4, o);
+                if (pre && dxout) st4(dxout + row * a.H, c4, f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre));
             }
         }
     }
@@ -361,6 +382,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void act_bwd_bf16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ aux, bf16_t* __restrict__ dz, int64_t n4, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 d = ld4(dy, i), z = ld4(aux, i);
+        float4 o;
+        if (act == YTVLN_EPI_GELU) o = make_float4(d.x * dgelu_erf(z.x), d.y * dgelu_erf(z.y), d.z * dgelu_erf(z.z), d.w * dgelu_erf(z.w));
+        else o = make_float4(z.x > 0.f ? d.x : 0.f, z.y > 0.f ? d.y : 0.f, z.z > 0.f ? d.z : 0.f, z.w > 0.f ? d.w : 0.f);
+        st4(dz, i, o);
+    }
+}
+
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
                                                       const int64_t* rng, int64_t site) {
     const DropKey key = make_drop_key(rng, site);
@@ -375,19 +406,20 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
-template <int MODE>
+template <int MODE, typename XT = float, typename YT = float>
 static int launch_ln(const LnArgs& a, hipStream_t s) {
     const int nv = (int)cdiv(a.H / 4, 64);
     const int grid = (int)std::min<int64_t>(cdiv(a.rows, 4), 4096);
-    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, MODE>), dim3(grid), dim3(256), 0, s, a);
-    else if (nv <= 2) hipLaunchKernelGGL((ln_fwd_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a);
-    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_fwd_kernel<8, MODE>), dim3(grid), dim3(256), 0, s, a);
+    if (nv <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, MODE, XT, YT>), dim3(grid), dim3(256), 0, s, a);
+    else if (nv <= 2) hipLaunchKernelGGL((ln_fwd_kernel<2, MODE, XT, YT>), dim3(grid), dim3(256), 0, s, a);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, MODE, XT, YT>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_fwd_kernel<8, MODE, XT, YT>), dim3(grid), dim3(256), 0, s, a);
     return 0;
 }
 
 static inline bool ln_shape_ok(int H) { return H > 0 && H % 4 == 0 && H <= 2048; }
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
 }  // namespace ytvln
 
@@ -462,7 +494,7 @@ extern "C" int ytvln_ln_bwd_f32(const float* dy, const float* s, const float* me
     YT_REQUIRE(!(p_pre > 0.f) || dx, "ln_bwd: p_pre > 0 needs dx");
     if (rows == 0) return 0;
     LnBwdArgs a;
-    a.dy = dy; a.s = s; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.ds = ds; a.dx = dx; a.partial = partial;
+    a.dy = dy; a.s = s; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.ds = ds; a.dx = dx; a.ds_f32 = nullptr; a.partial = partial;
     a.rows = rows; a.H = H; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
     const int nb = ytvln_ln_bwd_blocks(rows);
     a.rows_per_block = (int)cdiv(rows, nb);
@@ -557,5 +589,94 @@ extern "C" int ytvln_dropout_f32(const float* x, float* y, int64_t n, float p, c
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4, 256), 4096))), dim3(256), 0,
                        as_stream(stream), x, y, n, p, rng, site);
     YT_LAUNCH_CHECK("dropout");
+    return 0;
+}
+
+// ---- bf16-resident path (BASELINE configs[4]): the same kernels on bf16 rows; statistics, gamma / beta and their gradients stay fp32 --------
+extern "C" int ytvln_ln_fwd_bf16(const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, uint16_t* y, uint16_t* s_out,
+                                 float* mean, float* rstd, int64_t rows, int H, float eps, float p_pre, float p_post, const int64_t* rng,
+                                 int64_t site, void* stream) {
+    YT_REQUIRE(x && gamma && beta && y, "ln_fwd_bf16: null pointer");
+    YT_REQUIRE(ln_shape_ok(H), "ln_fwd_bf16: H=%d unsupported (need H %% 4 == 0, H <= 2048)", H);
+    YT_REQUIRE(al8(x) && al8(y) && al16(gamma) && al16(beta) && (!res || al8(res)) && (!s_out || al8(s_out)), "ln_fwd_bf16: misaligned pointer");
+    YT_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "ln_fwd_bf16: dropout p out of range");
+    YT_REQUIRE(!(p_pre > 0.f || p_post > 0.f) || rng, "ln_fwd_bf16: dropout needs rng state");
+    if (rows == 0) return 0;
+    LnArgs a = {};
+    a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.H = H; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
+    launch_ln<LN_PLAIN, bf16_t, bf16_t>(a, as_stream(stream));
+    YT_LAUNCH_CHECK("ln_fwd_bf16");
+    return 0;
+}
+
+extern "C" int ytvln_text_embed_fwd_bf16(const int64_t* ids, const int64_t* type_ids, const float* word, const float* pos, const float* type,
+                                         const float* gamma, const float* beta, uint16_t* y, uint16_t* s_out, float* mean, float* rstd,
+                                         int64_t rows, int T, int H, float eps, float p_post, const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(ids && word && pos && type && gamma && beta && y, "text_embed_fwd_bf16: null pointer");
+    YT_REQUIRE(ln_shape_ok(H) && T > 0, "text_embed_fwd_bf16: bad shape H=%d T=%d", H, T);
+    YT_REQUIRE(al16(word) && al16(pos) && al16(type) && al8(y) && al16(gamma) && al16(beta) && (!s_out || al8(s_out)), "text_embed_fwd_bf16: misaligned pointer");
+    YT_REQUIRE(!(p_post > 0.f) || rng, "text_embed_fwd_bf16: dropout needs rng state");
+    if (rows == 0) return 0;
+    LnArgs a = {};
+    a.ids = ids; a.type_ids = type_ids; a.word = word; a.pos = pos; a.type = type; a.T = T;
+    a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.H = H; a.eps = eps; a.p_pre = 0.f; a.p_post = p_post; a.rng = rng; a.site = site;
+    launch_ln<LN_TEXT, float, bf16_t>(a, as_stream(stream));
+    YT_LAUNCH_CHECK("text_embed_fwd_bf16");
+    return 0;
+}
+
+extern "C" int ytvln_image_embed_fwd_bf16(const uint16_t* img, const float* loc, const float* W5, const float* b5, const float* W4, const float* b4,
+                                          const float* W2, const float* b2, const float* E, const float* gamma, const float* beta, uint16_t* y,
+                                          uint16_t* s_out, float* mean, float* rstd, int64_t rows, int H, float eps, float p_post,
+                                          const int64_t* rng, int64_t site, void* stream) {
+    YT_REQUIRE(img && loc && W5 && b5 && W4 && b4 && W2 && b2 && E && gamma && beta && y, "image_embed_fwd_bf16: null pointer");
+    YT_REQUIRE(ln_shape_ok(H), "image_embed_fwd_bf16: H=%d unsupported", H);
+    YT_REQUIRE(al8(img) && al16(loc) && al8(y) && al16(gamma) && al16(beta) && (!s_out || al8(s_out)), "image_embed_fwd_bf16: misaligned pointer");
+    YT_REQUIRE(!(p_post > 0.f) || rng, "image_embed_fwd_bf16: dropout needs rng state");
+    if (rows == 0) return 0;
+    LnArgs a = {};
+    a.x = img; a.loc = loc; a.W5 = W5; a.b5 = b5; a.W4 = W4; a.b4 = b4; a.W2 = W2; a.b2 = b2; a.E = E;
+    a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.H = H; a.eps = eps; a.p_pre = 0.f; a.p_post = p_post; a.rng = rng; a.site = site;
+    launch_ln<LN_IMAGE, bf16_t, bf16_t>(a, as_stream(stream));
+    YT_LAUNCH_CHECK("image_embed_fwd_bf16");
+    return 0;
+}
+
+extern "C" int ytvln_ln_bwd_bf16(const uint16_t* dy, const uint16_t* s, const float* mean, const float* rstd, const float* gamma, uint16_t* ds,
+                                 uint16_t* dx, float* ds_f32, float* partial, int64_t rows, int H, float p_pre, float p_post, const int64_t* rng,
+                                 int64_t site, void* stream) {
+    YT_REQUIRE(dy && s && mean && rstd && gamma && (ds || ds_f32) && partial, "ln_bwd_bf16: null pointer");
+    YT_REQUIRE(ln_shape_ok(H), "ln_bwd_bf16: H=%d unsupported", H);
+    YT_REQUIRE(al8(dy) && al8(s) && (!ds || al8(ds)) && al16(gamma) && (!dx || al8(dx)) && (!ds_f32 || al16(ds_f32)), "ln_bwd_bf16: misaligned pointer");
+    YT_REQUIRE(!(p_pre > 0.f || p_post > 0.f) || rng, "ln_bwd_bf16: dropout needs rng state");
+    YT_REQUIRE(!(p_pre > 0.f) || dx, "ln_bwd_bf16: p_pre > 0 needs dx");
+    if (rows == 0) return 0;
+    LnBwdArgs a;
+    a.dy = dy; a.s = s; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.ds = ds; a.dx = dx; a.ds_f32 = ds_f32; a.partial = partial;
+    a.rows = rows; a.H = H; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
+    const int nb = ytvln_ln_bwd_blocks(rows);
+    a.rows_per_block = (int)cdiv(rows, nb);
+    const int nv = (int)cdiv(H / 4, 64);
+    const size_t lds = (size_t)8 * H * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    if (nv <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1, bf16_t>), dim3(nb), dim3(256), lds, st, a);
+    else if (nv <= 2) hipLaunchKernelGGL((ln_bwd_kernel<2, bf16_t>), dim3(nb), dim3(256), lds, st, a);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_bwd_kernel<4, bf16_t>), dim3(nb), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<8, bf16_t>), dim3(nb), dim3(256), lds, st, a);
+    YT_LAUNCH_CHECK("ln_bwd_bf16");
+    return 0;
+}
+
+extern "C" int ytvln_act_bwd_bf16(const uint16_t* dy, const uint16_t* aux, uint16_t* dz, int64_t n, int act, void* stream) {
+    YT_REQUIRE(dy && aux && dz, "act_bwd_bf16: null pointer");
+    YT_REQUIRE(act == YTVLN_EPI_GELU || act == YTVLN_EPI_RELU, "act_bwd_bf16: bad act %d", act);
+    YT_REQUIRE(al8(dy) && al8(aux) && al8(dz) && n % 4 == 0, "act_bwd_bf16: pointers must be 8-byte aligned and n a multiple of 4");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4, 256), 4096))), dim3(256), 0,
+                       as_stream(stream), dy, aux, dz, n / 4, act);
+    YT_LAUNCH_CHECK("act_bwd_bf16");
     return 0;
 }

@@ -41,21 +41,27 @@ SIGNATURES = {
     "ytvln_scatter_add_rows_sorted_f32": [P, I64, P, P, I32, I32, P, I64, P],
     "ytvln_randomize_tokens": [P, P, I64, I32, I64, P, P, P, I64, P, P, P],
     "ytvln_randomize_regions": [P, I64, P, P, I64, I32, I32, P, P, I64, P, P, P],
-    "ytvln_attn_fwd_bf16": [P, I64, P, I64, P, I64, P, P, I64, P, I32, I32, I32, I32, I32, F32, F32, P, I64, P],
-    "ytvln_attn_bwd_bf16": [P, I64, P, I64, P, I64, P, P, P, I64, P, P, P, I64, P, I64, P, I64, I32, I32, I32, I32, I32,
-                           F32, F32, P, I64, P],
-    "ytvln_attn_fwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
-    "ytvln_attn_bwd_pair": [P, P, I32, I32, I32, F32, P, I32, P],
+    "ytvln_attn_fwd_bf16": [P, P, I32, I32, I32, F32, P, P],
+    "ytvln_attn_bwd_bf16": [P, P, I32, I32, I32, F32, P, P],
+    "ytvln_attn_fwd_pair": [P, P, I32, I32, I32, F32, P, P],
+    "ytvln_attn_bwd_pair": [P, P, I32, I32, I32, F32, P, P],
     "ytvln_gemm_plan": [I32, I32, I32, I32, I32, P, P, P],
     "ytvln_option_count": [],
     "ytvln_option_name": [I32],
     "ytvln_set_option": [P, I32],
     "ytvln_get_option": [P, P],
     "ytvln_gemm_plan_x3": [I32, I32, I32, I32, I32, P, P, P],
-    "ytvln_cast_bf16_dual": [P, I64, I32, I32, P, I64, P, I64, P],
-    "ytvln_cast_bf16_dual_colsum": [P, I64, I32, I32, P, I64, P, I64, P, P],
-    "ytvln_cast_bf16": [P, I64, I32, I32, I32, P, I64, P],
-    "ytvln_gemm_bf16_nt": [P, I64, P, I64, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, P],
+    "ytvln_gemm_bf16_workspace_elems": [I32, I32, I32, I32],
+    "ytvln_gemm_bf16": [P, I64, I32, P, I64, I32, P, I64, I32, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P, P, P],
+    "ytvln_cast_f32_bf16": [P, I64, I64, I32, P, I64, P],
+    "ytvln_ln_fwd_bf16": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],
+    "ytvln_ln_bwd_bf16": [P, P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, I64, P],
+    "ytvln_text_embed_fwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, P, I64, P],
+    "ytvln_image_embed_fwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, I64, P],
+    "ytvln_act_bwd_bf16": [P, P, P, I64, I32, P],
+    "ytvln_ce_bwd_bf16": [P, I64, P, I64, P, P, P, P, I64, I32, I32, P],
+    "ytvln_kl_bwd_bf16": [P, I64, P, I64, P, P, P, P, P, I64, I32, I32, P],
+    "ytvln_adamw_f32_bf16copy": [P, P, P, P, P, P, I32, P, F32, P],
     "ytvln_ln_fwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],
     "ytvln_ln_bwd_blocks": [I64],
     "ytvln_ln_bwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, I64, P],
@@ -86,7 +92,7 @@ SIGNATURES = {
     "ytvln_rccl_async_error": [P],
     "ytvln_rccl_destroy": [P],
 }
-RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
+RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
 DT_F32, DT_F64, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128

@@ -146,8 +146,9 @@ _MATMUL_PRECISION = "fp32"
 
 def set_matmul_precision(mode: str) -> None:
     """"fp32" (default, the reference's arithmetic: v_mfma_f32_32x32x2_f32), "bf16" or "fp32x3".
-    "bf16": dense projections stage their operands in bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE
-    config 5), attention feeds bf16 operands to the matrix cores; LayerNorm, softmax, losses, master weights, optimizer stay fp32.
+    "bf16" (BASELINE configs[4]): the bf16-RESIDENT path -- hidden states, their gradients and a copy of the weights live in HBM as bf16;
+    projections (ytvln_gemm_bf16) and attention (ytvln_attn_*_bf16) read them in place and write bf16, LayerNorm reads / writes bf16 rows;
+    accumulation, softmax, LayerNorm statistics, logits, losses, master weights, weight gradients and the optimizer stay fp32.
     "fp32x3": dense projections keep fp32 operands and split every value exactly into three bf16 terms in registers; each product is
     accumulated in fp32 from the six largest cross terms on the bf16 matrix instruction (YTVLN_GEMM_SPLIT_BF16X3: error per product
     of the order of one fp32 rounding).  Attention and everything else as in "fp32".  Process-wide switch, read at call time."""
@@ -161,63 +162,21 @@ def get_matmul_precision() -> str:
     return _MATMUL_PRECISION
 
 
-def _stage_bf16(X: Tensor, ld: int, rows: int, cols: int, transpose: bool) -> Tuple[Tensor, int]:
-    """bf16 copy of the fp32 matrix at X with the contraction index made contiguous and zero-padded to a multiple of 64."""
-    contract, other = (rows, cols) if transpose else (cols, rows)
-    ldo = (contract + 63) // 64 * 64
-    out = torch.empty((other, ldo), dtype=torch.bfloat16, device=X.device)
-    call("ytvln_cast_bf16", _ptr(X), ld, rows, cols, int(transpose), _ptr(out), ldo, _stream())
-    return out, ldo
-
-
-def _stage_bf16_dual(X: Tensor, ld: int, rows: int, cols: int, colsum_out: Optional[Tensor] = None):
-    """Both bf16 stagings of the fp32 matrix X [rows, cols] from ONE read: ([rows][cols->64], ld) and ([cols][rows->64], ld).
-    `colsum_out` = a [cols] tensor that receives the column sums of X (a bias gradient when X is dY): the staging pass leaves one partial
-    row per 64 rows, a small `colsum` over those finishes it -- instead of a second full read of X."""
-    ldp, ldt = (cols + 63) // 64 * 64, (rows + 63) // 64 * 64
-    plain = torch.empty((rows, ldp), dtype=torch.bfloat16, device=X.device)
-    trans = torch.empty((cols, ldt), dtype=torch.bfloat16, device=X.device)
-    if colsum_out is not None and _FUSED_BIAS_GRAD:
-        nblk = ldt // 64
-        part = torch.empty((nblk, cols), dtype=torch.float32, device=X.device)
-        call("ytvln_cast_bf16_dual_colsum", _ptr(X), ld, rows, cols, _ptr(plain), ldp, _ptr(trans), ldt, _ptr(part), _stream())
-        colsum(part, nblk, cols, cols, out=colsum_out)
-        return (plain, ldp), (trans, ldt), True
-    call("ytvln_cast_bf16_dual", _ptr(X), ld, rows, cols, _ptr(plain), ldp, _ptr(trans), ldt, _stream())
-    return (plain, ldp), (trans, ldt), False
-
-
-_FWD_DUAL = os.environ.get("YTVLN_BF16_FWD_DUAL", "1") != "0"      # experiment knob: 0 -> re-stage the inputs in backward
-
-
 def _bf16_eligible(M: int, N: int, K: int) -> bool:
+    """bf16 mode: does a projection whose INPUT arrives as fp32 (network inputs, pooled vectors) enter the bf16-resident path?  Large ones
+    do (the region-feature projection); the one- and two-column heads on the pooled vectors stay on the fp32 kernels."""
     return _MATMUL_PRECISION == "bf16" and M >= 64 and N >= 64 and K >= 64
 
 
-def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, A_staged=None,
-          B_staged=None, rowsum=None):
-    """`A_staged` / `B_staged` = (bf16 tensor [M][K->64] / [N][K->64], ld): the operand already staged by the caller (bf16 mode only;
-    see _stage_bf16_dual).  `rowsum` = an [M] tensor that should receive sum_k op(A)[m, k] (the bias gradient riding on a weight-gradient
-    GEMM, ytvln_gemm_f32_rowsum); returns True when the launch produced it, False when the caller has to run `colsum` itself."""
-    bf16 = _bf16_eligible(M, N, K)
-    Kw = (K + 63) // 64 * 32 if bf16 else K        # contraction length in 4-byte words, as the split-K planner counts it
-    key = (M, N, Kw, epi)
+def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, rowsum=None):
+    """fp32 operands (native fp32 matrix instruction, or the three-bf16-term form under "fp32x3").  `rowsum` = an [M] tensor that should
+    receive sum_k op(A)[m, k] (the bias gradient riding on a weight-gradient GEMM, ytvln_gemm_f32_rowsum); returns True when the launch
+    produced it, False when the caller has to run `colsum` itself."""
+    key = (M, N, K, epi)
     need = _WS_CACHE.get(key)
     if need is None:
-        need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, Kw, epi))
+        need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, K, epi))
     ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
-    if bf16:
-        if A_staged is not None:
-            Ab, la = A_staged
-        else:
-            Ab, la = _stage_bf16(A, lda, K, M, True) if transA else _stage_bf16(A, lda, M, K, False)       # -> [M][Kp]
-        if B_staged is not None:
-            Bb, lb = B_staged
-        else:
-            Bb, lb = _stage_bf16(B, ldb, N, K, False) if transB else _stage_bf16(B, ldb, K, N, True)   # -> [N][Kp]
-        call("ytvln_gemm_bf16_nt", _ptr(Ab), la, _ptr(Bb), lb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, M, N, la, epi, float(beta),
-             _ptr(ws), need, _stream())
-        return False
     if _MATMUL_PRECISION == "fp32x3":
         flags = int(flags) | GEMM_SPLIT_BF16X3
     if rowsum is not None and _FUSED_BIAS_GRAD:
@@ -274,10 +233,11 @@ class ArenaSlot:
     """Where a parameter lives inside the optimizer's flat arenas.  Attached to the Parameter object as `_ytvln_slot` by
     ytvln.optimization.AdamW; `written` (shared per arena) records which gradient slots a GEMM has already written directly
     since the last optimizer step / zero_grad, so a weight used twice before one backward falls back to the additive path."""
-    __slots__ = ("flat_p", "flat_g", "off", "numel", "written")
+    __slots__ = ("flat_p", "flat_g", "off", "numel", "written", "owner")
 
-    def __init__(self, flat_p, flat_g, off, numel, written):
+    def __init__(self, flat_p, flat_g, off, numel, written, owner=None):
         self.flat_p, self.flat_g, self.off, self.numel, self.written = flat_p, flat_g, off, numel, written
+        self.owner = owner          # weakref to the optimizer that owns the arenas (its bf16 weight arena: bf16_arena())
 
     def valid_for(self, t) -> bool:
         return t.numel() == self.numel and t.data_ptr() == self.flat_p.data_ptr() + 4 * self.off
@@ -449,12 +409,7 @@ class LinearFn(torch.autograd.Function):
         else:
             y, ldy = torch.empty((M, N), dtype=torch.float32, device=x.device), N
         z = torch.empty_like(y) if (epi == EPI_GELU and need_grad) else None
-        # bf16 mode: the input is read ONCE for both of its bf16 roles -- [M][K] for this GEMM and [K][M] (kept for backward) for
-        # the weight-gradient GEMM -- instead of a second fp32 pass over it in backward
-        st_p = ctx.x_t = None
-        if _FWD_DUAL and ctx.needs_input_grad[1] and _bf16_eligible(M, N, K) and _bf16_eligible(N, K, M):
-            st_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K)[:2]
-        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi, A_staged=st_p)
+        _gemm(x2, lda, 0, weight, weight.stride(0), 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
         ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
         ctx.in_shape = x.shape
         ctx.targets = _targets_of(weight)
@@ -479,23 +434,20 @@ class LinearFn(torch.autograd.Function):
         else:
             dy, ldy, flags, _ = _rows_of_grad(dy, M, N)
         dx = dw = db = None
-        st_p = st_t = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if want_db:
             db = _direct_grad(ctx.btargets, (N,))
             if db is None:
                 db = torch.empty(N, dtype=torch.float32, device=dy.device)
         db_done = False
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _bf16_eligible(M, K, N) and _bf16_eligible(N, K, M):
-            st_p, st_t, db_done = _stage_bf16_dual(dy, ldy, M, N, colsum_out=db if want_db else None)   # dY read once for all its roles
         if ctx.needs_input_grad[0]:
             acc = _accumulate_target(dres, M, K, dy)
             if acc is not None:          # dx = d(residual) + dY W, written over the residual branch's gradient
-                _gemm(dy, ldy, 0, weight, weight.stride(0), 0, acc, K, M, K, N, beta=1.0, flags=flags, A_staged=st_p)
+                _gemm(dy, ldy, 0, weight, weight.stride(0), 0, acc, K, M, K, N, beta=1.0, flags=flags)
                 dx = acc.view(ctx.in_shape)
             else:
                 dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-                _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags, A_staged=st_p)
+                _gemm(dy, ldy, 0, weight, weight.stride(0), 0, dx, K, M, K, N, flags=flags)
                 dx = dx.view(ctx.in_shape)
                 if dres is not None:
                     dx = dx + dres.reshape(ctx.in_shape)
@@ -503,22 +455,33 @@ class LinearFn(torch.autograd.Function):
             dw = _direct_grad(ctx.targets, (N, K))
             if dw is None:
                 dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            # db = column sums of dY = row sums of the A operand (dY^T) of this launch: rides on the GEMM when it can (fp32 modes; in bf16
-            # mode it rode on the staging pass above)
-            db_done = _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, A_staged=st_t, B_staged=ctx.x_t,
-                            rowsum=db if (want_db and not db_done) else None) or db_done
-            ctx.x_t = None
+            # db = column sums of dY = row sums of the A operand (dY^T) of this launch: rides on the GEMM when it can
+            db_done = _gemm(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, rowsum=db if want_db else None)
         if want_db and not db_done:
             colsum(dy, M, N, ldy, out=db)
         return dx, dw, db, None, None
 
 
-def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tensor:
+def _wants_bf16(x: Tensor, weight: Tensor) -> bool:
+    """bf16-resident path for this projection?  Yes when its input already is a bf16 hidden state; in bf16 mode also for a LARGE projection
+    whose input arrives as fp32 (the 2048-d region features: cast once on the way in)."""
+    if x.dtype == torch.bfloat16:
+        return True
+    K = x.shape[-1]
+    return x.dtype == torch.float32 and _bf16_eligible(x.numel() // max(K, 1), weight.shape[0], K)
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None, out_fp32: bool = False) -> Tensor:
+    """`out_fp32` only matters on the bf16-resident path: the output leaves the path as fp32 (logits for the loss kernels, pooled vectors)."""
+    if _wants_bf16(x, weight):
+        return LinearBf16Fn.apply(x, weight, bias, act, False, out_fp32)
     return LinearFn.apply(x, weight, bias, act)
 
 
 def linear_res(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tuple[Tensor, Tensor]:
     """(linear(x, ...), x): use the second value for the residual connection around the sublayer (see LinearFn)."""
+    if _wants_bf16(x, weight):
+        return LinearBf16Fn.apply(x, weight, bias, act, True, False)
     return LinearFn.apply(x, weight, bias, act, True)
 
 
@@ -535,14 +498,9 @@ class FFNFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         h = torch.empty((M, I), dtype=torch.float32, device=x.device)
         z = torch.empty_like(h) if need_grad else None
-        # bf16 mode: x and h are each read once for both bf16 roles (this GEMM's [M][K] operand, the weight-gradient GEMM's [K][M])
-        dual = _FWD_DUAL and need_grad and _bf16_eligible(M, I, K) and _bf16_eligible(I, K, M) and _bf16_eligible(M, N, I) and _bf16_eligible(N, I, M)
-        sx_p, ctx.x_t = _stage_bf16_dual(x2, lda, M, K)[:2] if dual else (None, None)
-        _gemm(x2, lda, 0, w1, w1.stride(0), 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU, A_staged=sx_p)
-        del sx_p
+        _gemm(x2, lda, 0, w1, w1.stride(0), 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU)
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        sh_p, ctx.h_t = _stage_bf16_dual(h, I, M, I)[:2] if dual else (None, None)
-        _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2, A_staged=sh_p)
+        _gemm(h, I, 0, w2, w2.stride(0), 1, y, N, M, N, I, bias=b2)
         ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
         ctx.targets = (_targets_of(w1), _targets_of(w2), _targets_of(b1), _targets_of(b2))
         ctx.save_for_backward(x2, w1, w2, z, h)
@@ -560,51 +518,376 @@ class FFNFn(torch.autograd.Function):
             dy = dy.contiguous()
         dev = dy.device
         dz = torch.empty((M, I), dtype=torch.float32, device=dev)
-        dual = _bf16_eligible(M, I, N) and _bf16_eligible(N, I, M) and _bf16_eligible(M, K, I) and _bf16_eligible(I, K, M)
         db2 = _direct_grad(ctx.targets[3], (N,))
         if db2 is None:
             db2 = torch.empty(N, dtype=torch.float32, device=dev)
         db1 = _direct_grad(ctx.targets[2], (I,))
         if db1 is None:
             db1 = torch.empty(I, dtype=torch.float32, device=dev)
-        sy_p, sy_t, db2_done = _stage_bf16_dual(dy, N, M, N, colsum_out=db2) if dual else (None, None, False)   # bf16: db2 rides on the staging
-        _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU, A_staged=sy_p)   # dH * gelu'(z)
+        _gemm(dy, N, 0, w2, w2.stride(0), 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU)   # dH * gelu'(z)
         dw2 = _direct_grad(ctx.targets[1], (N, I))
         if dw2 is None:
             dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
-        # fp32 modes: db2 rides on the dW2 GEMM
-        if not (_gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, A_staged=sy_t, B_staged=ctx.h_t, rowsum=None if db2_done else db2) or db2_done):
+        if not _gemm(dy, N, 1, h, I, 0, dw2, I, N, I, M, rowsum=db2):          # db2 rides on the dW2 GEMM
             colsum(dy, M, N, N, out=db2)
-        ctx.h_t = None
-        sz_p, sz_t, db1_done = _stage_bf16_dual(dz, I, M, I, colsum_out=db1) if dual else (None, None, False)
         dx = None
         if ctx.needs_input_grad[0]:
             acc = _accumulate_target(dres, M, K, dy)      # (dy is consumed by now, but it may be retained / hooked upstream)
             if acc is not None:          # the residual around the FFN: accumulate into its gradient (see LinearFn)
-                _gemm(dz, I, 0, w1, w1.stride(0), 0, acc, K, M, K, I, beta=1.0, A_staged=sz_p)
+                _gemm(dz, I, 0, w1, w1.stride(0), 0, acc, K, M, K, I, beta=1.0)
                 dx = acc.view(ctx.in_shape)
             else:
                 dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-                _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I, A_staged=sz_p)
+                _gemm(dz, I, 0, w1, w1.stride(0), 0, dx, K, M, K, I)
                 dx = dx.view(ctx.in_shape)
                 if dres is not None:
                     dx = dx + dres.reshape(ctx.in_shape)
         dw1 = _direct_grad(ctx.targets[0], (I, K))
         if dw1 is None:
             dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
-        if not (_gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, A_staged=sz_t, B_staged=ctx.x_t, rowsum=None if db1_done else db1) or db1_done):
+        if not _gemm(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, rowsum=db1):
             colsum(dz, M, I, I, out=db1)
-        ctx.x_t = None
         return dx, dw1, db1, dw2, db2, None
 
 
 def ffn(x, w1, b1, w2, b2) -> Tensor:
+    if x.dtype == torch.bfloat16:
+        return FFNBf16Fn.apply(x, w1, b1, w2, b2)
     return FFNFn.apply(x, w1, b1, w2, b2)
 
 
 def ffn_res(x, w1, b1, w2, b2) -> Tuple[Tensor, Tensor]:
     """(ffn(x, ...), x) -- the second value feeds the residual add behind the FFN (see LinearFn)."""
+    if x.dtype == torch.bfloat16:
+        return FFNBf16Fn.apply(x, w1, b1, w2, b2, True)
     return FFNFn.apply(x, w1, b1, w2, b2, True)
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16-resident path (BASELINE configs[4]; set_matmul_precision("bf16")): hidden states, their gradients and a copy of the weights
+# are bf16 tensors in HBM; ytvln_gemm_bf16 / ytvln_attn_*_bf16 / ytvln_ln_*_bf16 read and write them in place.  No operand is
+# staged, cast or transposed per call: the producer of a tensor writes the bf16 its consumers read.
+# ------------------------------------------------------------------------------------------------------------------
+_BF16 = torch.bfloat16
+_BF16_WS_CACHE = {}
+_DT_CODE = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16}
+
+
+def _pad8(n: int) -> int:
+    """Leading dimension (elements) of a bf16 row buffer whose width is not a multiple of 8: rounded up to 64, the padding ZERO."""
+    return n if n % 8 == 0 else (n + 63) // 64 * 64
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    """bf16 copy (round to nearest even) of a contiguous fp32 tensor: network inputs entering the bf16-resident path, parameters outside the
+    optimizer's arenas, small fp32 gradients coming back from the fp32 heads."""
+    _check(x, "x")
+    xc = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(xc.shape, dtype=_BF16, device=x.device)
+    cols = xc.shape[-1] if xc.dim() > 1 else xc.numel()
+    rows = xc.numel() // max(cols, 1)
+    if xc.numel():
+        call("ytvln_cast_f32_bf16", _ptr(xc), cols, rows, cols, out.data_ptr(), cols, _stream())
+    return out
+
+
+def _bf16_weight(weight: Tensor) -> Tensor:
+    """The bf16 copy of a weight operand ([out, in], contiguous).  Parameters that live in the optimizer's flat arena (after the first
+    optimizer step: all that receive gradients) have their copy in a bf16 arena at the same offsets, refreshed by the AdamW kernel itself
+    (ytvln_adamw_f32_bf16copy) -- a packed Q|K|V operand is then a zero-copy view of it.  Everything else (the first eager steps, frozen
+    or inference-only parameters) is cast on the spot and cached against the parameter's version counter."""
+    targets = _targets_of(weight)
+    if targets:
+        first = _slot_of(targets[0])
+        if first is not None and first.owner is not None:
+            off, ok = first.off, True
+            for t in targets:
+                sl = _slot_of(t)
+                if sl is None or sl.flat_p is not first.flat_p or sl.off != off:
+                    ok = False
+                    break
+                off += sl.numel
+            opt = first.owner() if ok else None
+            if opt is not None:
+                pb = opt.bf16_arena(targets)
+                if pb is not None:
+                    return pb[first.off:off].view(weight.shape)
+        # not (all) in the arena: per-parameter cache keyed by (storage pointer, version)
+        key = tuple((t.data_ptr(), t._version) for t in targets)
+        holder = targets[0]
+        cached = getattr(holder, "_ytvln_bf16_cache", None)
+        if cached is not None and cached[0] == key and cached[1].shape == weight.shape:
+            return cached[1]
+        wb = cast_bf16(weight.detach())
+        if not torch.cuda.is_current_stream_capturing():
+            holder._ytvln_bf16_cache = (key, wb)
+        return wb
+    return cast_bf16(weight.detach())
+
+
+def _gemm_bf16(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, ldaux=0, epi=EPI_NONE, beta=0.0, flags=0, rowsum=None):
+    """ytvln_gemm_bf16: bf16 operands read in place (transA = 1 / transB = 0: the contraction index is the operand's ROW, gathered by the
+    transposing LDS read), fp32 accumulation, C bf16 or fp32.  Returns True when `rowsum` ([M] fp32: sum_k op(A)[m, k]) was produced."""
+    key = (M, N, K, epi)
+    need = _BF16_WS_CACHE.get(key)
+    if need is None:
+        need = _BF16_WS_CACHE[key] = int(_lib.load().ytvln_gemm_bf16_workspace_elems(M, N, K, epi))
+    ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None
+    done = ctypes.c_int(0)
+    call("ytvln_gemm_bf16", A.data_ptr(), lda, int(transA), B.data_ptr(), ldb, int(transB), C.data_ptr(), ldc, _DT_CODE[C.dtype], _ptr(bias),
+         aux.data_ptr() if aux is not None else None, ldaux, M, N, K, epi, float(beta), _ptr(ws), need, int(flags),
+         _ptr(rowsum) if rowsum is not None else None, ctypes.byref(done) if rowsum is not None else None, _stream())
+    return bool(done.value)
+
+
+def _rows2d_bf16(x: Tensor) -> Tuple[Tensor, int, int, int]:
+    """View a bf16 tensor as [M, K] rows with unit inner stride and a leading dimension that is a multiple of 8."""
+    K = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+        return x, x.shape[0], K, x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x, x.numel() // max(K, 1), K, K
+
+
+def _grad_rows_bf16(dy: Tensor, M: int, N: int):
+    """(dy as bf16 [M, N] rows, leading dimension, GEMM flags).  bf16 gradients with a padded leading dimension come from the loss kernels
+    (ytvln_ce_bwd_bf16 / ytvln_kl_bwd_bf16: zero padding written by the kernel) and are used in place; fp32 gradients (the small heads on the
+    pooled vectors) are cast; anything unaligned is repacked into a zero-padded buffer."""
+    if dy.dtype == torch.float32:
+        dy = cast_bf16(dy.reshape(M, N))
+    d2 = dy.reshape(M, N)
+    if d2.stride(1) == 1 and d2.stride(0) % 8 == 0 and d2.data_ptr() % 16 == 0 and (d2.stride(0) == N or
+                                                                                   _ZERO_PADDED.get(d2.untyped_storage().data_ptr()) == d2.stride(0)):
+        return d2, d2.stride(0), (GEMM_A_ZERO_PADDED if d2.stride(0) != N else 0)
+    ld = _pad8(N)
+    if ld == N:
+        return d2.contiguous(), N, 0
+    full = torch.zeros((M, ld), dtype=_BF16, device=dy.device)
+    full[:, :N].copy_(d2)
+    return full[:, :N], ld, GEMM_A_ZERO_PADDED
+
+
+def _alloc_rows_bf16(M: int, N: int, device):
+    """[M, N] bf16 view with leading dimension _pad8(N); the caller's kernel writes zeros into the padding (and that is remembered)."""
+    ld = _pad8(N)
+    if ld == N:
+        return torch.empty((M, N), dtype=_BF16, device=device), N
+    full = torch.empty((M, ld), dtype=_BF16, device=device)
+    key = full.untyped_storage().data_ptr()
+    _ZERO_PADDED[key] = ld
+    _weakref.finalize(full, _ZERO_PADDED.pop, key, None)
+    return full[:, :N], ld
+
+
+class LinearBf16Fn(torch.autograd.Function):
+    """y = act(x W^T + b) on the bf16-resident path (same contract as LinearFn, incl. `passthrough`).  x: bf16 hidden states (or fp32 network
+    inputs, cast once); W: the bf16 copy of the fp32 master weight; y: bf16, or fp32 when `out_fp32` (logits, pooled vectors).  Backward:
+    dX = dY W and dW = dY^T X read dY, W and X as they lie in HBM (k-major operands through the transposing LDS read); dW and db are fp32
+    and go straight into the gradient arena; db rides on the dW launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, passthrough=False, out_fp32=False):
+        ctx.set_materialize_grads(False)
+        ctx.passthrough = bool(passthrough)
+        ctx.x_was_f32 = x.dtype == torch.float32
+        xb = cast_bf16(x) if ctx.x_was_f32 else x
+        _check(xb, "x", _BF16)
+        x2, M, K, lda = _rows2d_bf16(xb)
+        _check(weight, "weight")
+        N = weight.shape[0]
+        assert weight.shape[1] == K, (weight.shape, K)
+        wb = _bf16_weight(weight)
+        need_grad = any(ctx.needs_input_grad)
+        epi = _ACT[act]
+        if out_fp32:
+            y, ldy = _alloc_rows(M, N, x.device)
+        else:
+            y, ldy = torch.empty((M, N), dtype=_BF16, device=x.device), N
+        z = torch.empty((M, N), dtype=_BF16, device=x.device) if (epi == EPI_GELU and need_grad) else None
+        _gemm_bf16(x2, lda, 0, wb, K, 1, y, ldy, M, N, K, bias=bias, aux=z, ldaux=N, epi=epi)
+        ctx.epi, ctx.dims, ctx.lda, ctx.has_bias = epi, (M, N, K), lda, bias is not None
+        ctx.in_shape = x.shape
+        ctx.targets = _targets_of(weight)
+        ctx.btargets = _targets_of(bias) if bias is not None else None
+        # the ReLU backward needs the sign of the OUTPUT: a bf16 copy of it when the output itself leaves as fp32
+        aux = z if epi == EPI_GELU else ((y if y.dtype == _BF16 else cast_bf16(y)) if (epi == EPI_RELU and need_grad) else None)
+        ctx.save_for_backward(x2, weight, aux)
+        out = _view_rows_as(y, ldy, tuple(x.shape[:-1]) + (N,))
+        return (out, x) if ctx.passthrough else out
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
+        if dy is None:
+            return (dres if ctx.needs_input_grad[0] else None), None, None, None, None, None
+        x2, weight, aux = ctx.saved_tensors
+        M, N, K = ctx.dims
+        dy, ldy, flags = _grad_rows_bf16(dy, M, N)
+        if ctx.epi != EPI_NONE:
+            if ldy != N:
+                dy, ldy, flags = dy.contiguous(), N, 0
+            dz = torch.empty((M, N), dtype=_BF16, device=dy.device)
+            call("ytvln_act_bwd_bf16", dy.data_ptr(), aux.data_ptr(), dz.data_ptr(), dy.numel(), ctx.epi, _stream())
+            dy = dz
+        dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_db:
+            db = _direct_grad(ctx.btargets, (N,))
+            if db is None:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+        if ctx.needs_input_grad[0]:
+            wb = _bf16_weight(weight)
+            acc = None
+            if not ctx.x_was_f32 and dres is not None and dres.dtype == _BF16 and dres.is_contiguous() and dres.numel() == M * K and \
+                    not _overlaps(dres, dy):
+                acc = dres.view(M, K)
+            if acc is not None:          # dx = d(residual) + dY W, accumulated over the residual branch's gradient (beta = 1)
+                _gemm_bf16(dy, ldy, 0, wb, K, 0, acc, K, M, K, N, beta=1.0, flags=flags)
+                dx = acc.view(ctx.in_shape)
+            else:
+                dx = torch.empty((M, K), dtype=_BF16, device=dy.device)
+                _gemm_bf16(dy, ldy, 0, wb, K, 0, dx, K, M, K, N, flags=flags)
+                dx = dx.view(ctx.in_shape)
+                if dres is not None:
+                    dx = dx + dres.reshape(ctx.in_shape)
+                if ctx.x_was_f32:
+                    dx = dx.float()
+        db_done = False
+        if ctx.needs_input_grad[1]:
+            dw = _direct_grad(ctx.targets, (N, K))
+            if dw is None:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            # dW[N, K] = dY^T X: both operands k-major (the contraction index M is their row); db = row sums of dY^T ride on the launch
+            db_done = _gemm_bf16(dy, ldy, 1, x2, ctx.lda, 0, dw, K, N, K, M, flags=flags, rowsum=db if want_db else None)
+        if want_db and not db_done:
+            colsum(dy.float() if ldy == N else dy.contiguous().float(), M, N, N, out=db)
+        return dx, dw, db, None, None, None
+
+
+class FFNBf16Fn(torch.autograd.Function):
+    """out = gelu(x W1^T + b1) W2^T + b2 on the bf16-resident path (BertIntermediate + BertOutput.dense, vilbert.py:351-354, 365): x, the
+    GELU pre-activation z, the hidden h and out are bf16; the backward fuses GELU' into the epilogue of the dX GEMM of the second projection."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, passthrough=False):
+        ctx.set_materialize_grads(False)
+        ctx.passthrough = bool(passthrough)
+        _check(x, "x", _BF16)
+        x2, M, K, lda = _rows2d_bf16(x)
+        I, N = w1.shape[0], w2.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        dev = x.device
+        h = torch.empty((M, I), dtype=_BF16, device=dev)
+        z = torch.empty((M, I), dtype=_BF16, device=dev) if need_grad else None
+        _gemm_bf16(x2, lda, 0, _bf16_weight(w1), K, 1, h, I, M, I, K, bias=b1, aux=z, ldaux=I, epi=EPI_GELU)
+        y = torch.empty((M, N), dtype=_BF16, device=dev)
+        _gemm_bf16(h, I, 0, _bf16_weight(w2), I, 1, y, N, M, N, I, bias=b2)
+        ctx.dims, ctx.lda, ctx.in_shape = (M, K, I, N), lda, x.shape
+        ctx.targets = (_targets_of(w1), _targets_of(w2), _targets_of(b1), _targets_of(b2))
+        ctx.save_for_backward(x2, w1, w2, z, h)
+        out = y.view(*x.shape[:-1], N)
+        return (out, x) if ctx.passthrough else out
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
+        if dy is None:
+            return (dres if ctx.needs_input_grad[0] else None), None, None, None, None, None
+        x2, w1, w2, z, h = ctx.saved_tensors
+        M, K, I, N = ctx.dims
+        dy, ldy, _ = _grad_rows_bf16(dy, M, N)
+        dev = dy.device
+        dz = torch.empty((M, I), dtype=_BF16, device=dev)
+        db2 = _direct_grad(ctx.targets[3], (N,))
+        if db2 is None:
+            db2 = torch.empty(N, dtype=torch.float32, device=dev)
+        db1 = _direct_grad(ctx.targets[2], (I,))
+        if db1 is None:
+            db1 = torch.empty(I, dtype=torch.float32, device=dev)
+        _gemm_bf16(dy, ldy, 0, _bf16_weight(w2), I, 0, dz, I, M, I, N, aux=z, ldaux=I, epi=EPI_MUL_DGELU)   # dH * gelu'(z)
+        dw2 = _direct_grad(ctx.targets[1], (N, I))
+        if dw2 is None:
+            dw2 = torch.empty((N, I), dtype=torch.float32, device=dev)
+        if not _gemm_bf16(dy, ldy, 1, h, I, 0, dw2, I, N, I, M, rowsum=db2):
+            colsum(dy.float(), M, N, N, out=db2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            acc = None
+            if dres is not None and dres.dtype == _BF16 and dres.is_contiguous() and dres.numel() == M * K and not _overlaps(dres, dy):
+                acc = dres.view(M, K)
+            if acc is not None:          # the residual around the FFN: accumulate into its gradient
+                _gemm_bf16(dz, I, 0, _bf16_weight(w1), K, 0, acc, K, M, K, I, beta=1.0)
+                dx = acc.view(ctx.in_shape)
+            else:
+                dx = torch.empty((M, K), dtype=_BF16, device=dev)
+                _gemm_bf16(dz, I, 0, _bf16_weight(w1), K, 0, dx, K, M, K, I)
+                dx = dx.view(ctx.in_shape)
+                if dres is not None:
+                    dx = dx + dres.reshape(ctx.in_shape)
+        dw1 = _direct_grad(ctx.targets[0], (I, K))
+        if dw1 is None:
+            dw1 = torch.empty((I, K), dtype=torch.float32, device=dev)
+        if not _gemm_bf16(dz, I, 1, x2, ctx.lda, 0, dw1, K, I, K, M, rowsum=db1):
+            colsum(dz.float(), M, I, I, out=db1)
+        return dx, dw1, db1, dw2, db2, None
+
+
+def _ln_bwd_bf16(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site, gb_targets=None, want_bf16=True, want_f32=False):
+    """-> (ds bf16 | None, dx bf16 (= ds when p_pre == 0), ds fp32 | None, dgamma, dbeta)."""
+    if dy.dtype != _BF16:
+        dy = cast_bf16(dy.reshape(rows, H))
+    dy = dy.reshape(rows, H)
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    ds = torch.empty((rows, H), dtype=_BF16, device=dy.device) if want_bf16 else None
+    dx = torch.empty((rows, H), dtype=_BF16, device=dy.device) if p_pre > 0 else None
+    ds32 = torch.empty((rows, H), dtype=torch.float32, device=dy.device) if want_f32 else None
+    nb = _lib.load().ytvln_ln_bwd_blocks(rows)
+    partial = torch.empty((nb, 2 * H), dtype=torch.float32, device=dy.device)
+    call("ytvln_ln_bwd_bf16", dy.data_ptr(), s.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(gamma), ds.data_ptr() if ds is not None else None,
+         dx.data_ptr() if dx is not None else None, _ptr(ds32), _ptr(partial), rows, H, float(p_pre), float(p_post),
+         _ptr(rng) if rng is not None else None, int(site), _stream())
+    gb = colsum(partial, nb, 2 * H, 2 * H, out=_direct_grad(gb_targets, (2 * H,)))
+    return ds, (dx if dx is not None else ds), ds32, gb[:H], gb[H:]
+
+
+class AddLayerNormBf16Fn(torch.autograd.Function):
+    """y = LN(dropout(x) + residual) on bf16 rows (statistics, gamma / beta and their gradients fp32); saves s = dropout(x) + residual as bf16."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p_pre, p_post, rng, site):
+        ctx.set_materialize_grads(False)
+        _check(x, "x", _BF16)
+        H = x.shape[-1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        rc = None
+        if res is not None:
+            _check(res, "residual", _BF16)
+            rc = res if res.is_contiguous() else res.contiguous()
+        rows = xc.numel() // H
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(xc)
+        s = torch.empty_like(xc) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        rstd = torch.empty_like(mean) if need_grad else None
+        call("ytvln_ln_fwd_bf16", xc.data_ptr(), rc.data_ptr() if rc is not None else None, _ptr(gamma), _ptr(beta), y.data_ptr(),
+             s.data_ptr() if s is not None else None, _ptr(mean), _ptr(rstd), rows, H, float(eps), float(p_pre), float(p_post),
+             _ptr(rng) if rng is not None else None, int(site), _stream())
+        ctx.meta = (rows, H, p_pre, p_post, site, res is not None)
+        ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
+        ctx.save_for_backward(s, mean, rstd, gamma, rng)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 9
+        s, mean, rstd, gamma, rng = ctx.saved_tensors
+        rows, H, p_pre, p_post, site, has_res = ctx.meta
+        ds, dx, _, dg, db = _ln_bwd_bf16(dy, s, mean, rstd, gamma, rows, H, p_pre, p_post, rng, site, ctx.gb)
+        shape = dy.shape
+        return (dx.view(shape) if ctx.needs_input_grad[0] else None,
+                ds.view(shape) if (has_res and ctx.needs_input_grad[1]) else None, dg, db, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -665,8 +948,9 @@ def add_layer_norm(x, res, gamma, beta, eps=1e-12, p_pre=0.0, p_post=0.0, drop: 
     if (p_pre > 0 or p_post > 0) and drop is None:
         raise RuntimeError("dropout requested without a DropoutState")
     use = drop is not None and (p_pre > 0 or p_post > 0)
-    return AddLayerNormFn.apply(x, res, gamma, beta, eps, p_pre if use else 0.0, p_post if use else 0.0,
-                                drop.tensor if use else None, drop.next_site() if use else 0)
+    fn = AddLayerNormBf16Fn if x.dtype == torch.bfloat16 else AddLayerNormFn
+    return fn.apply(x, res, gamma, beta, eps, p_pre if use else 0.0, p_post if use else 0.0,
+                    drop.tensor if use else None, drop.next_site() if use else 0)
 
 
 class TextEmbedFn(torch.autograd.Function):
@@ -683,13 +967,14 @@ class TextEmbedFn(torch.autograd.Function):
         tt = _i64(type_ids, "token_type_ids") if type_ids is not None else None
         rows = N * T
         need_grad = any(ctx.needs_input_grad)
-        y = torch.empty((N, T, H), dtype=torch.float32, device=word.device)
+        bf16 = _MATMUL_PRECISION == "bf16"          # bf16-resident path: the hidden states leave the embedding as bf16
+        y = torch.empty((N, T, H), dtype=torch.bfloat16 if bf16 else torch.float32, device=word.device)
         s = torch.empty_like(y) if need_grad else None
         mean = torch.empty(rows, dtype=torch.float32, device=word.device) if need_grad else None
         rstd = torch.empty_like(mean) if need_grad else None
-        call("ytvln_text_embed_fwd_f32", _ptr(ids), _ptr(tt), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma), _ptr(beta), _ptr(y),
-             _ptr(s), _ptr(mean), _ptr(rstd), rows, T, H, float(eps), float(p_post), _ptr(rng) if rng is not None else None,
-             int(site), _stream())
+        call("ytvln_text_embed_fwd_bf16" if bf16 else "ytvln_text_embed_fwd_f32", _ptr(ids), _ptr(tt), _ptr(word), _ptr(pos), _ptr(typ),
+             _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s), _ptr(mean), _ptr(rstd), rows, T, H, float(eps), float(p_post),
+             _ptr(rng) if rng is not None else None, int(site), _stream())
         ctx.meta = (N, T, H, p_post, site, word.shape, pos.shape, typ.shape)
         ctx.save_for_backward(ids, tt, s, mean, rstd, gamma, rng)
         return y
@@ -701,7 +986,10 @@ class TextEmbedFn(torch.autograd.Function):
         ids, tt, s, mean, rstd, gamma, rng = ctx.saved_tensors
         N, T, H, p_post, site, wshape, pshape, tshape = ctx.meta
         rows = N * T
-        ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
+        if s.dtype == torch.bfloat16:          # bf16-resident path: the table-gradient kernels below read an fp32 copy of ds
+            _, _, ds, dg, db = _ln_bwd_bf16(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site, want_bf16=False, want_f32=True)
+        else:
+            ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
         dev = ds.device
         dword = torch.zeros(wshape, dtype=torch.float32, device=dev)
         # token ids repeat inside a batch: sorted (stable) so that one wave owns each id's run -- no atomics, reproducible sums
@@ -748,7 +1036,8 @@ class ImageEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps, p_post, rng, site):
         ctx.set_materialize_grads(False)
-        _check(img, "img")
+        bf16 = img.dtype == torch.bfloat16          # bf16-resident path: img is the bf16 output of the feature projection
+        _check(img, "img", img.dtype if bf16 else torch.float32)
         _check(loc, "image_loc")
         H = img.shape[-1]
         imgc = img if img.is_contiguous() else img.contiguous()
@@ -762,7 +1051,7 @@ class ImageEmbedFn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=img.device) if need_grad else None
         rstd = torch.empty_like(mean) if need_grad else None
         ws = [w if w.is_contiguous() else w.contiguous() for w in (W5, W4, W2, E)]
-        call("ytvln_image_embed_fwd_f32", _ptr(imgc), _ptr(locc), _ptr(ws[0]), _ptr(b5), _ptr(ws[1]), _ptr(b4), _ptr(ws[2]), _ptr(b2),
+        call("ytvln_image_embed_fwd_bf16" if bf16 else "ytvln_image_embed_fwd_f32", _ptr(imgc), _ptr(locc), _ptr(ws[0]), _ptr(b5), _ptr(ws[1]), _ptr(b4), _ptr(ws[2]), _ptr(b2),
              _ptr(ws[3]), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(s), _ptr(mean), _ptr(rstd), rows, H, float(eps), float(p_post),
              _ptr(rng) if rng is not None else None, int(site), _stream())
         ctx.meta = (rows, H, p_post, site, E.shape[0])
@@ -775,13 +1064,17 @@ class ImageEmbedFn(torch.autograd.Function):
             return (None,) * 15
         locc, s, mean, rstd, gamma, rng = ctx.saved_tensors
         rows, H, p_post, site, KT = ctx.meta
-        ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
+        dimg = None
+        if s.dtype == torch.bfloat16:          # bf16-resident path: bf16 ds for the feature projection's backward, an fp32 copy for the small kernels below
+            dimg, _, ds, dg, db = _ln_bwd_bf16(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site, want_bf16=True, want_f32=True)
+        else:
+            ds, _, dg, db = _ln_bwd(dy, s, mean, rstd, gamma, rows, H, 0.0, p_post, rng, site)
         dev = ds.device
         dwall = torch.empty((H, 12), dtype=torch.float32, device=dev)
         _gemm(ds, H, 1, locc, 12, 0, dwall, 12, H, 12, rows)               # ds^T . loc  -> [H, 12]
         dbias = colsum(ds, rows, H, H)
         dE = colsum_by_index(ds, rows, H, H, KT, idx_f32=locc, idx_stride=12, idx_f32_offset=11)
-        return (ds.view(dy.shape), None, dwall[:, 0:5].contiguous(), dbias, dwall[:, 5:9].contiguous(), dbias,
+        return ((dimg if dimg is not None else ds).view(dy.shape), None, dwall[:, 0:5].contiguous(), dbias, dwall[:, 5:9].contiguous(), dbias,
                 dwall[:, 9:11].contiguous(), dbias, dE, dg, db, None, None, None, None)
 
 
@@ -865,9 +1158,42 @@ def dropout(x: Tensor, p: float, training: bool, drop: Optional[DropoutState]) -
 # ------------------------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------------------------
+def _eptr(t: Optional[Tensor], offset_elems: int = 0):
+    return None if t is None else t.data_ptr() + t.element_size() * offset_elems
+
+
+def _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=None, lse=None, ctx_in=None, dctx=None,
+                  lse_in=None, delta=None, dq=None, dq_off=0, lddq=0, dk=None, dk_off=0, lddk=0, dv=None, dv_off=0, lddv=0):
+    """One `ytvln_attn_problem` record (include/ytvln.h); q / k / v / ctx / gradients are fp32 or bf16 tensors (offsets in elements)."""
+    pr = _lib.AttnProblem()
+    pr.q, pr.k, pr.v, pr.mask = _eptr(q, q_off), _eptr(k, k_off), _eptr(v, v_off), _ptr(mask)
+    pr.ctx, pr.lse = _eptr(ctx), _ptr(lse)
+    pr.ctx_in, pr.dctx, pr.lse_in, pr.delta = _eptr(ctx_in), _eptr(dctx), _ptr(lse_in), _ptr(delta)
+    pr.dq, pr.dk, pr.dv = _eptr(dq, dq_off), _eptr(dk, dk_off), _eptr(dv, dv_off)
+    o = ctx if ctx is not None else ctx_in
+    pr.ldq, pr.ldk, pr.ldv, pr.ldo, pr.lddq, pr.lddk, pr.lddv = ldq, ldk, ldv, o.shape[-1], lddq, lddk, lddv
+    pr.Tq, pr.Tk, pr.p_drop, pr.site = Tq, Tk, float(p), int(site)
+    return pr
+
+
+def _attn_launch(backward: bool, bf16: bool, pa, pb, N, heads, d, scale, rng):
+    """One launch over one problem (pb = None) or the two directions of BertBiAttention."""
+    rp = _ptr(rng) if rng is not None else None
+    if bf16:
+        call("ytvln_attn_bwd_bf16" if backward else "ytvln_attn_fwd_bf16", ctypes.addressof(pa), ctypes.addressof(pb) if pb is not None else None,
+             N, heads, d, float(scale), rp, _stream())
+    else:
+        call("ytvln_attn_bwd_pair" if backward else "ytvln_attn_fwd_pair", ctypes.addressof(pa), ctypes.addressof(pb), N, heads, d, float(scale),
+             rp, _stream())
+
+
 def _attn_fwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, N, heads, Tq, Tk, d, scale, p, rng, site):
     lse = torch.empty((N, heads, Tq), dtype=torch.float32, device=out.device)
-    call("ytvln_attn_fwd_bf16" if (_MATMUL_PRECISION == "bf16" and d % 8 == 0) else "ytvln_attn_fwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), out.shape[-1],
+    if q.dtype == torch.bfloat16:
+        _attn_launch(False, True, _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=out, lse=lse), None,
+                     N, heads, d, scale, rng)
+        return lse
+    call("ytvln_attn_fwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), out.shape[-1],
          _ptr(lse), N, heads, Tq, Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
     return lse
 
@@ -875,28 +1201,14 @@ def _attn_fwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, N, heads, 
 def _attn_bwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, dout, lse, dq, dq_off, lddq, dk, dk_off, lddk, dv, dv_off,
               lddv, N, heads, Tq, Tk, d, scale, p, rng, site):
     delta = torch.empty_like(lse)
-    call("ytvln_attn_bwd_bf16" if (_MATMUL_PRECISION == "bf16" and d % 8 == 0) else "ytvln_attn_bwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), _ptr(dout),
+    if q.dtype == torch.bfloat16:
+        _attn_launch(True, True, _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx_in=out, dctx=dout,
+                                               lse_in=lse, delta=delta, dq=dq, dq_off=dq_off, lddq=lddq, dk=dk, dk_off=dk_off, lddk=lddk,
+                                               dv=dv, dv_off=dv_off, lddv=lddv), None, N, heads, d, scale, rng)
+        return
+    call("ytvln_attn_bwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), _ptr(dout),
          out.shape[-1], _ptr(lse), _ptr(delta), _ptr(dq, dq_off), lddq, _ptr(dk, dk_off), lddk, _ptr(dv, dv_off), lddv, N, heads, Tq,
          Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
-
-
-def _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=None, lse=None, ctx_in=None, dctx=None,
-                  lse_in=None, delta=None, dq=None, dq_off=0, lddq=0, dk=None, dk_off=0, lddk=0, dv=None, dv_off=0, lddv=0):
-    pr = _lib.AttnProblem()
-    pr.q, pr.k, pr.v, pr.mask = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), _ptr(mask)
-    pr.ctx, pr.lse = _ptr(ctx), _ptr(lse)
-    pr.ctx_in, pr.dctx, pr.lse_in, pr.delta = _ptr(ctx_in), _ptr(dctx), _ptr(lse_in), _ptr(delta)
-    pr.dq, pr.dk, pr.dv = _ptr(dq, dq_off), _ptr(dk, dk_off), _ptr(dv, dv_off)
-    o = ctx if ctx is not None else ctx_in
-    pr.ldq, pr.ldk, pr.ldv, pr.ldo, pr.lddq, pr.lddk, pr.lddv = ldq, ldk, ldv, o.shape[-1], lddq, lddk, lddv
-    pr.Tq, pr.Tk, pr.p_drop, pr.site = Tq, Tk, float(p), int(site)
-    return pr
-
-
-def _attn_pair(name, pa, pb, N, heads, d, scale, rng):
-    import ctypes
-    call(name, ctypes.addressof(pa), ctypes.addressof(pb), N, heads, d, float(scale), _ptr(rng) if rng is not None else None,
-         int(_MATMUL_PRECISION == "bf16" and d % 8 == 0), _stream())
 
 
 def attn_probs(q, q_off, ldq, k, k_off, ldk, mask, lse, N, heads, Tq, Tk, d, scale) -> Tensor:
@@ -912,12 +1224,14 @@ class SelfAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, mask, N, T, heads, p, rng, site):
         ctx.set_materialize_grads(False)
-        _check(qkv, "qkv")
+        _check(qkv, "qkv", qkv.dtype if qkv.dtype == torch.bfloat16 else torch.float32)
         assert qkv.is_contiguous() and qkv.dim() == 2 and qkv.shape[0] == N * T
         H = qkv.shape[1] // 3
         d = H // heads
+        if qkv.dtype == torch.bfloat16 and d not in (64, 128):
+            raise NotImplementedError(f"bf16-resident attention is built for head dimensions 64 and 128 (got {d}); use the fp32 path")
         scale = 1.0 / math.sqrt(d)
-        out = torch.empty((N * T, H), dtype=torch.float32, device=qkv.device)
+        out = torch.empty((N * T, H), dtype=qkv.dtype, device=qkv.device)
         lse = _attn_fwd(qkv, 0, 3 * H, qkv, H, 3 * H, qkv, 2 * H, 3 * H, mask, out, N, heads, T, T, d, scale, p, rng, site)
         ctx.meta = (N, T, heads, H, d, scale, p, site)
         ctx.save_for_backward(qkv, mask, out, lse, rng)
@@ -931,6 +1245,8 @@ class SelfAttentionFn(torch.autograd.Function):
         qkv, mask, out, lse, rng = ctx.saved_tensors
         N, T, heads, H, d, scale, p, site = ctx.meta
         dout = dout if dout.is_contiguous() else dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = dout.to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         _attn_bwd(qkv, 0, 3 * H, qkv, H, 3 * H, qkv, 2 * H, 3 * H, mask, out, dout, lse, dqkv, 0, 3 * H, dqkv, H, 3 * H, dqkv, 2 * H,
                   3 * H, N, heads, T, T, d, scale, p, rng, site)
@@ -947,21 +1263,24 @@ class CoAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q1, kv1, q2, kv2, mask1, mask2, N, R, T, heads, p1, p2, rng, site1, site2):
+        bf16 = q1.dtype == torch.bfloat16
         for t, nme in ((q1, "q1"), (kv1, "kv1"), (q2, "q2"), (kv2, "kv2")):
-            _check(t, nme)
+            _check(t, nme, torch.bfloat16 if bf16 else torch.float32)
             assert t.is_contiguous() and t.dim() == 2
         Hb = q1.shape[1]
         d = Hb // heads
+        if bf16 and d not in (64, 128):
+            raise NotImplementedError(f"bf16-resident attention is built for head dimensions 64 and 128 (got {d}); use the fp32 path")
         scale = 1.0 / math.sqrt(d)
-        ctx1 = torch.empty((N * T, Hb), dtype=torch.float32, device=q1.device)
-        ctx2 = torch.empty((N * R, Hb), dtype=torch.float32, device=q1.device)
+        ctx1 = torch.empty((N * T, Hb), dtype=q1.dtype, device=q1.device)
+        ctx2 = torch.empty((N * R, Hb), dtype=q1.dtype, device=q1.device)
         lse1 = torch.empty((N, heads, T), dtype=torch.float32, device=q1.device)
         lse2 = torch.empty((N, heads, R), dtype=torch.float32, device=q1.device)
         # both directions in one launch (text queries over regions | region queries over text)
-        _attn_pair("ytvln_attn_fwd_pair",
-                   _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx=ctx1, lse=lse1),
-                   _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx=ctx2, lse=lse2),
-                   N, heads, d, scale, rng)
+        _attn_launch(False, bf16,
+                     _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx=ctx1, lse=lse1),
+                     _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx=ctx2, lse=lse2),
+                     N, heads, d, scale, rng)
         ctx.meta = (N, R, T, heads, Hb, d, scale, p1, p2, site1, site2)
         ctx.save_for_backward(q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng)
         ctx.mark_non_differentiable(lse1, lse2)
@@ -978,7 +1297,7 @@ class CoAttentionFn(torch.autograd.Function):
             d2 = d2 if d2.is_contiguous() else d2.contiguous()
             gq2, gkv1, gq1, gkv2 = torch.empty_like(q2), torch.empty_like(kv1), torch.empty_like(q1), torch.empty_like(kv2)
             delta1, delta2 = torch.empty_like(lse1), torch.empty_like(lse2)
-            _attn_pair("ytvln_attn_bwd_pair",
+            _attn_launch(True, q1.dtype == torch.bfloat16,
                        _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx_in=ctx1, dctx=d1, lse_in=lse1,
                                      delta=delta1, dq=gq2, lddq=Hb, dk=gkv1, lddk=2 * Hb, dv=gkv1, dv_off=Hb, lddv=2 * Hb),
                        _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx_in=ctx2, dctx=d2, lse_in=lse2,
@@ -1016,6 +1335,7 @@ class CrossEntropyFn(torch.autograd.Function):
         out = torch.empty(2, dtype=torch.float32, device=dev)
         call("ytvln_ce_fwd_f32", _ptr(lg), ld, _ptr(tg), int(ignore_index), _ptr(row_lse), _ptr(row_loss), _ptr(out), M, V, _stream())
         ctx.meta = (M, V, ld, int(ignore_index), logits.shape)
+        ctx.bf16_grad = _MATMUL_PRECISION == "bf16" and M * V >= (1 << 16)      # bf16-resident path: the (large) logit gradient leaves as bf16
         ctx.save_for_backward(lg, tg, row_lse, out)
         return out[0]
 
@@ -1026,6 +1346,10 @@ class CrossEntropyFn(torch.autograd.Function):
         lg, tg, row_lse, out = ctx.saved_tensors
         M, V, ld, ign, shape = ctx.meta
         g = g.reshape(1).contiguous().float()
+        if ctx.bf16_grad:          # rounded once, zero padding written by the kernel: feeds ytvln_gemm_bf16 as it stands
+            dl, ldd = _alloc_rows_bf16(M, V, lg.device)
+            call("ytvln_ce_bwd_bf16", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), dl.data_ptr(), ldd, M, V, _stream())
+            return _view_rows_as(dl, ldd, shape), None, None
         dl, ldd = _alloc_rows(M, V, lg.device, zero_pad=True)
         call("ytvln_ce_bwd_f32", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dl), ldd, M, V, _stream())
         return _view_rows_as(dl, ldd, shape), None, None
@@ -1051,6 +1375,7 @@ class KLMaskedFn(torch.autograd.Function):
         out = torch.empty(2, dtype=torch.float32, device=dev)
         call("ytvln_kl_fwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(row_loss), _ptr(out), M, Cc, _stream())
         ctx.meta = (M, Cc, ld, ldt, pred.shape)
+        ctx.bf16_grad = _MATMUL_PRECISION == "bf16" and M * Cc >= (1 << 16)
         ctx.save_for_backward(pr, tg, mk, row_lse, out)
         return out[0]
 
@@ -1061,6 +1386,10 @@ class KLMaskedFn(torch.autograd.Function):
         pr, tg, mk, row_lse, out = ctx.saved_tensors
         M, Cc, ld, ldt, shape = ctx.meta
         g = g.reshape(1).contiguous().float()
+        if ctx.bf16_grad:
+            dp, ldd = _alloc_rows_bf16(M, Cc, pr.device)
+            call("ytvln_kl_bwd_bf16", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), dp.data_ptr(), ldd, M, Cc, _stream())
+            return _view_rows_as(dp, ldd, shape), None, None
         dp, ldd = _alloc_rows(M, Cc, pr.device, zero_pad=True)
         call("ytvln_kl_bwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dp), ldd, M, Cc, _stream())
         return _view_rows_as(dp, ldd, shape), None, None
@@ -1103,8 +1432,14 @@ def bce_with_logits(x: Tensor, t: Tensor, pos_weight: Optional[Tensor] = None) -
 # ------------------------------------------------------------------------------------------------------------------
 # optimizer kernel
 # ------------------------------------------------------------------------------------------------------------------
-def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, chunks: Tensor, nchunks: int, hyper: Tensor, grad_scale: float = 1.0):
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, chunks: Tensor, nchunks: int, hyper: Tensor, grad_scale: float = 1.0,
+               p_bf16: Optional[Tensor] = None):
+    """`p_bf16`: the bf16 parameter arena of the bf16-resident path (same offsets): refreshed by the same kernel pass."""
     for t, nme in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyper, "hyper")):
         _check(t, nme)
+    if p_bf16 is not None:
+        call("ytvln_adamw_f32_bf16copy", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p_bf16.data_ptr(), chunks.data_ptr(), int(nchunks), _ptr(hyper),
+             float(grad_scale), _stream())
+        return
     call("ytvln_adamw_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), chunks.data_ptr(), int(nchunks), _ptr(hyper), float(grad_scale),
          _stream())

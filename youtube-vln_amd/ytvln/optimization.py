@@ -146,15 +146,41 @@ class AdamW(Optimizer):
                 p.grad = flat["g"][o:o + n].view(p.shape)
                 st["exp_avg"] = flat["m"][o:o + n].view(p.shape)
                 st["exp_avg_sq"] = flat["v"][o:o + n].view(p.shape)
-        self._arena = dict(flat, index=index, ids=[id(p) for _, p in members])
+        self._arena = dict(flat, index=index, ids=[id(p) for _, p in members], pb=None, pb_versions={})
         self._launch = None
         del old
         # let the weight-gradient GEMMs write straight into the gradient arena and the packed projections alias the
         # parameter arena: every member parameter carries its slot (ytvln.ops.ArenaSlot)
         self._written = set()
+        import weakref
+        me = weakref.ref(self)
         for _, p in members:
             o, n = index[id(p)]
-            p._ytvln_slot = ops.ArenaSlot(flat["p"], flat["g"], o, n, self._written)
+            p._ytvln_slot = ops.ArenaSlot(flat["p"], flat["g"], o, n, self._written, me)
+
+    def bf16_arena(self, params=None):
+        """The bf16 copy of the parameter arena (bf16-resident path, ytvln.ops._bf16_weight): created on first use by one cast of the whole
+        arena, from then on refreshed by the AdamW kernel itself (ytvln_adamw_f32_bf16copy).  `params`: the parameters about to be read --
+        if torch modified one of them in place since the copy was made (load_state_dict, manual edits: their version counters moved), its
+        slice is cast again.  None before the arena exists."""
+        a = self._arena
+        if a is None:
+            return None
+        if a["pb"] is None:
+            a["pb"] = torch.empty(a["p"].numel(), dtype=torch.bfloat16, device=a["p"].device)
+            ops.call("ytvln_cast_f32_bf16", a["p"].data_ptr(), a["p"].numel(), 1, a["p"].numel(), a["pb"].data_ptr(), a["p"].numel(), ops._stream())
+            a["pb_versions"] = {id(p): p._version for _, p in self._members()}
+        vers = a["pb_versions"]
+        for p in (params or ()):
+            rng = a["index"].get(id(p))
+            if rng is None:
+                return None
+            if vers.get(id(p)) != p._version:
+                if id(p) in vers:          # modified behind the optimizer's back: refresh this slice
+                    o, n = rng
+                    ops.call("ytvln_cast_f32_bf16", a["p"].data_ptr() + 4 * o, n, 1, n, a["pb"].data_ptr() + 2 * o, n, ops._stream())
+                vers[id(p)] = p._version
+        return a["pb"]
 
     def _ensure_arena(self):
         members = self._members()
@@ -242,7 +268,7 @@ class AdamW(Optimizer):
     def _launch_kernels(self):
         a = self._arena
         for c in self._launch:
-            ops.adamw_step(a["p"], a["g"], a["m"], a["v"], c["table"], c["n"], c["hyper"], self.grad_scale)
+            ops.adamw_step(a["p"], a["g"], a["m"], a["v"], c["table"], c["n"], c["hyper"], self.grad_scale, p_bf16=a["pb"])
 
     @torch.no_grad()
     def step(self, closure=None):

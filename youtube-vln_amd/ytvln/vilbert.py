@@ -586,7 +586,7 @@ class _PoolerBase(nn.Module):
 
     def forward(self, hidden_states):
         # first token of every row, read in place through the GEMM's leading dimension (no gather copy)
-        return ops.linear(hidden_states[:, 0], self.dense.weight, self.dense.bias, "relu")
+        return ops.linear(hidden_states[:, 0], self.dense.weight, self.dense.bias, "relu", out_fp32=True)      # (fp32 out: only matters on the bf16-resident path)
 
 
 class BertTextPooler(_PoolerBase):
@@ -634,7 +634,7 @@ class BertLMPredictionHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
 
     def forward(self, hidden_states):
-        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.bias)
+        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.bias, out_fp32=True)       # logits feed the fp32 loss kernels
 
 
 class BertOnlyMLMHead(nn.Module):
@@ -662,7 +662,7 @@ class BertImagePredictionHead(nn.Module):
         self.decoder = nn.Linear(config.v_hidden_size, config.v_target_size)
 
     def forward(self, hidden_states):
-        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.decoder.bias)
+        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.decoder.bias, out_fp32=True)
 
 
 class BertPreTrainingHeads(nn.Module):
