@@ -622,7 +622,7 @@ def main():
         "metric": "pretrain samples/sec (traj-instr pairs)", "value": round(value, 3), "unit": "pairs/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * elapsed / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16": "bf16 activations / gradients / weight copies in HBM, bf16 MFMA, f32 accumulate / softmax / LayerNorm statistics / logits / master weights / optimizer",
+        "dtype": {"fp32": "f32", "bf16": "bf16 activations / gradients / logits / weight copies in HBM, bf16 MFMA, f32 accumulate / softmax / LayerNorm statistics / loss reductions / master weights / optimizer",
                   "fp32x3": "f32 operands split exactly into 3 bf16 terms in registers, 6 bf16 MFMAs per product, f32 accumulate (projections); "
                             "f32 everywhere else"}[a.precision], "data": "synthetic",
         "config": {"workload": a.workload, **({"gradient_exchange": ("ytvln_rccl_* (C ABI, " + os.path.basename(runner.comm.library) + ")") if runner.comm is not None

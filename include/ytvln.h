@@ -261,9 +261,12 @@ int ytvln_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* target, int
                      float* row_loss, float* out, int M, int V, void* stream);
 int ytvln_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
                      const float* out, const float* gout, float* dlogits, int64_t ldd, int M, int V, void* stream);
-/* the same gradient rounded to bf16, with ZEROS written to the padding columns [V, ldd): the buffer feeds ytvln_gemm_bf16 as a zero-padded
- * operand (YTVLN_GEMM_A_ZERO_PADDED) as it stands (bf16-resident path) */
-int ytvln_ce_bwd_bf16(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
+/* bf16-resident path (BASELINE configs[4]): the same two kernels on BF16 logits (what the decoders write there); the loss, row_lse and out
+ * stay fp32; the gradient is bf16 and ZEROS are written to its padding columns [V, ldd), so the buffer feeds ytvln_gemm_bf16 as a zero-padded
+ * operand (YTVLN_GEMM_A_ZERO_PADDED) as it stands */
+int ytvln_ce_fwd_bf16(const uint16_t* logits, int64_t ld, const int64_t* target, int64_t ignore_index, float* row_lse,
+                      float* row_loss, float* out, int M, int V, void* stream);
+int ytvln_ce_bwd_bf16(const uint16_t* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
                       const float* out, const float* gout, uint16_t* dlogits, int64_t ldd, int M, int V, void* stream);
 
 /* Masked KL of utils_init.py:117-128: sum_rows mask * sum_c t*(log t - log_softmax(pred)) / max(1, sum mask). */
@@ -272,8 +275,11 @@ int ytvln_kl_fwd_f32(const float* pred, int64_t ld, const float* target, int64_t
 int ytvln_kl_bwd_f32(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask,
                      const float* row_lse, const float* out, const float* gout, float* dpred, int64_t ldd, int M,
                      int C, void* stream);
-int ytvln_kl_bwd_bf16(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, const float* row_lse,
-                      const float* out, const float* gout, uint16_t* dpred, int64_t ldd, int M, int C, void* stream);   /* bf16 + zeroed padding, as ytvln_ce_bwd_bf16 */
+/* bf16 predictions in, bf16 gradient + zeroed padding out, as ytvln_ce_*_bf16 (targets stay fp32) */
+int ytvln_kl_fwd_bf16(const uint16_t* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, float* row_lse,
+                      float* row_loss, float* out, int M, int C, void* stream);
+int ytvln_kl_bwd_bf16(const uint16_t* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, const float* row_lse,
+                      const float* out, const float* gout, uint16_t* dpred, int64_t ldd, int M, int C, void* stream);
 
 /* F.binary_cross_entropy_with_logits(x, t, pos_weight) with mean reduction (utils_init.py:143, 160-161). n <= 65536.
  * pos_weight is a DEVICE scalar or NULL.  bwd writes dx. */

@@ -562,41 +562,6 @@ def test_gemm_zero_padded_tails(dev, lib):
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb,epi", [
-    (256, 192, 128, 0, 1, 0), (300, 200, 100, 0, 1, 0), (300, 200, 100, 0, 0, 0), (300, 200, 100, 1, 0, 0), (260, 132, 72, 1, 1, 0),
-    (512, 384, 256, 0, 1, 1), (200, 1601, 320, 0, 1, 0), (128, 256, 4096, 1, 0, 0),
-    (3600, 3592, 128, 0, 1, 0), (3592, 3600, 192, 1, 0, 0),       # these two run on the 256x256 tile (ragged last tile row / column)
-    (1024, 768, 16384, 1, 0, 0), (1000, 520, 12288, 1, 0, 0)])    # weight-gradient shapes: 256x256 tiles with split-K (12 x 21, 12 x 21 ragged)
-def test_gemm_bf16_staged(dev, lib, M, N, K, ta, tb, epi):
-    """bf16-staged projections (BASELINE config 5): exact product of the bf16-rounded operands, accumulated in fp32.
-    Reference: the same rounded operands multiplied in fp64.  Tolerance = fp32 accumulation noise, 2e-6 * sqrt(K) * |a||b|."""
-    from ytvln import ops
-    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
-    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
-    B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    C = torch.empty(M, N, device=dev)
-    aux = torch.empty(M, N, device=dev) if epi else None
-    ops.set_matmul_precision("bf16")
-    try:
-        ops._gemm(A, A.stride(0), ta, B, B.stride(0), tb, C, N, M, N, K, bias=bias, aux=aux, ldaux=N, epi=epi)
-    finally:
-        ops.set_matmul_precision("fp32")
-    Ar = (A.t() if ta else A).bfloat16().double().cpu()
-    Br = (B if tb else B.t()).bfloat16().double().cpu()
-    ref = Ar @ Br.t() + bias.double().cpu()
-    tol = 2e-6 * (K ** 0.5) * 4.0 + 1e-5
-    if epi:
-        assert float((aux.double().cpu() - ref).abs().max()) < tol
-        ref = torch.nn.functional.gelu(ref)
-    err = float((C.double().cpu() - ref).abs().max())
-    assert err < tol, (err, tol)
-    # and it is NOT the fp32 product: the staging really rounds (guards against a silent fp32 fallback)
-    full = (A.t() if ta else A).double().cpu() @ (B if tb else B.t()).double().cpu().t() + bias.double().cpu()
-    if not epi:
-        assert float((C.double().cpu() - full).abs().max()) > 1e-3
-
-
-@pytest.mark.parametrize("M,N,K,ta,tb,epi", [
     (384, 256, 256, 0, 1, 0), (300, 200, 96, 0, 0, 0), (300, 200, 96, 1, 0, 0), (260, 132, 64, 1, 1, 0), (512, 384, 256, 0, 1, 1),
     (128, 256, 4096, 1, 0, 0), (1000, 520, 160, 0, 1, 3),
     (3600, 3592, 128, 0, 1, 0), (4096, 1024, 512, 0, 0, 0), (3080, 1024, 96, 0, 1, 1),      # 256-row tiles
@@ -731,8 +696,10 @@ def test_edge_cases_and_loud_failures(dev, lib):
         ops.linear(torch.randn(4, 16), torch.randn(8, 16, device=dev))
     with pytest.raises(RuntimeError, match="float32"):
         ops.linear(torch.randn(4, 16, device=dev, dtype=torch.float64), torch.randn(8, 16, device=dev))
-    with pytest.raises(RuntimeError, match="multiple of 64|rounded up to 64"):
-        call("ytvln_cast_bf16", A.data_ptr(), 16, 8, 16, 0, C.data_ptr(), 16, None)
+    with pytest.raises(RuntimeError, match="output type"):          # the bf16-resident GEMM: C is bf16 or fp32, nothing else
+        call("ytvln_gemm_bf16", A.data_ptr(), 16, 0, A.data_ptr(), 16, 1, C.data_ptr(), 8, 7, None, None, 0, 8, 8, 16, 0, 0.0, None, 0, 0, None, None, None)
+    with pytest.raises(RuntimeError, match="head dim"):             # ... and its attention kernels exist for d = 64 / 128
+        ops.SelfAttentionFn.apply(torch.zeros(8, 48, device=dev, dtype=torch.bfloat16), torch.zeros(1, 8, device=dev), 1, 8, 1, 0.0, None, 0)
     # empty row sets through the row kernels
     out = torch.empty(0, 16, device=dev)
     call("ytvln_gather_rows_f32", A.data_ptr(), 16, None, 0, 16, out.data_ptr(), None)
@@ -828,46 +795,6 @@ def test_expand_options_matches_host_expansion(dev, lib):
     assert torch.equal(pr.cpu(), ep) and torch.equal(m.cpu(), em)
 
 
-@pytest.mark.parametrize("N,heads,d,Tq,Tk", [(2, 8, 128, 288, 288), (2, 8, 128, 80, 288), (2, 8, 128, 288, 80), (3, 12, 64, 80, 80),
-                                             (1, 3, 32, 33, 65), (1, 2, 8, 6, 9)])
-def test_attention_bf16_operands(dev, lib, N, heads, d, Tq, Tk):
-    """bf16-operand attention (opt-in, BASELINE config 5) against the fp64 reference on the SAME fp32 inputs.  Stated tolerance for
-    this mode: relative L2 <= 1e-2 forward, <= 2e-2 for dQ / dK / dV (q, k, v, the probabilities and dS are rounded to bf16 --
-    2^-9 relative -- before each contraction; accumulation, softmax and lse stay fp32).  The result must also DIFFER from the fp32
-    kernel's (guards against a silent fp32 fallback)."""
-    from ytvln import ops
-    H = heads * d
-    A = rnd(dev, N * Tq, 3 * H, seed=1)
-    B = rnd(dev, N * Tk, 3 * H, seed=2)
-    mask = torch.zeros(N, Tk, device=dev)
-    mask[0, Tk - max(1, Tk // 4):] = -10000.0
-    scale = 1 / math.sqrt(d)
-    outs = {}
-    for mode in ("fp32", "bf16"):
-        ops.set_matmul_precision(mode)
-        try:
-            out = torch.empty(N * Tq, H, device=dev)
-            lse = ops._attn_fwd(A, 0, 3 * H, B, H, 3 * H, B, 2 * H, 3 * H, mask, out, N, heads, Tq, Tk, d, scale, 0.0, None, 0)
-            dout = rnd(dev, N * Tq, H, seed=3)
-            gA, gB = torch.zeros_like(A), torch.zeros_like(B)
-            ops._attn_bwd(A, 0, 3 * H, B, H, 3 * H, B, 2 * H, 3 * H, mask, out, dout, lse, gA, 0, 3 * H, gB, H, 3 * H, gB, 2 * H, 3 * H,
-                          N, heads, Tq, Tk, d, scale, 0.0, None, 0)
-        finally:
-            ops.set_matmul_precision("fp32")
-        outs[mode] = (out, gA[:, :H].clone(), gB[:, H:2 * H].clone(), gB[:, 2 * H:].clone())
-    qd = A[:, :H].double().view(N, Tq, H).requires_grad_(True)
-    kd = B[:, H:2 * H].double().reshape(N, Tk, H).requires_grad_(True)
-    vd = B[:, 2 * H:].double().reshape(N, Tk, H).requires_grad_(True)
-    ref, _ = ref_attention(qd, kd, vd, mask.double(), heads)
-    ref.backward(rnd(dev, N * Tq, H, seed=3).double().view(N, Tq, H))
-    o, dq, dk, dv = outs["bf16"]
-    assert rel_l2(o.view(N, Tq, H), ref) < 1e-2, rel_l2(o.view(N, Tq, H), ref)
-    assert rel_l2(dq.reshape(N, Tq, H), qd.grad) < 2e-2, rel_l2(dq.reshape(N, Tq, H), qd.grad)
-    assert rel_l2(dk.reshape(N, Tk, H), kd.grad) < 2e-2, rel_l2(dk.reshape(N, Tk, H), kd.grad)
-    assert rel_l2(dv.reshape(N, Tk, H), vd.grad) < 2e-2, rel_l2(dv.reshape(N, Tk, H), vd.grad)
-    assert rel_l2(o, outs["fp32"][0]) > 1e-5, "bf16 attention reproduced the fp32 kernel: the bf16 path did not run"
-
-
 def test_gemm_splitk_xcd_layout_does_not_change_results(dev, lib):
     """Split-K workgroups are numbered split-major per XCD (decode_tile; option GEMM_SPLIT_MAP = 0 restores the old split-fastest order): the
     layout decides only WHERE a (tile, split) pair runs, so products, fused row sums and a beta = 1 accumulation are bit-identical
@@ -897,43 +824,6 @@ def test_gemm_splitk_xcd_layout_does_not_change_results(dev, lib):
         finally:
             _lib.set_option("GEMM_SPLIT_MAP", prev)
     assert digests[0] == digests[1], "the XCD layout of split-K workgroups changed the results"
-
-
-@pytest.mark.parametrize("rows,cols", [(256, 128), (300, 200), (65, 1601), (4480, 768), (70, 30)])
-def test_cast_bf16_dual_equals_separate_stagings(dev, lib, rows, cols):
-    """One pass producing both bf16 stagings == the plain and the transposing staging kernels, bit for bit (zero tails included)."""
-    from ytvln import ops
-    x = torch.randn(rows, cols + 8, device=dev)[:, :cols]                    # a strided view: leading dimension cols + 8
-    (p, ldp), (t, ldt), _ = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
-    p2, ldp2 = ops._stage_bf16(x, x.stride(0), rows, cols, False)
-    t2, ldt2 = ops._stage_bf16(x, x.stride(0), rows, cols, True)
-    assert (ldp, ldt) == (ldp2, ldt2)
-    assert torch.equal(p.view(torch.int16), p2.view(torch.int16)) and torch.equal(t.view(torch.int16), t2.view(torch.int16))
-    assert torch.equal(p[:, :cols].float(), x.bfloat16().float()) and bool((p[:, cols:] == 0).all()) and bool((t[:, rows:] == 0).all())
-
-
-@pytest.mark.parametrize("rows,cols", [(256, 128), (300, 200), (65, 1601), (4480, 768), (70, 30), (16128, 1024)])
-def test_cast_bf16_dual_colsum_rides_on_the_staging(dev, lib, rows, cols):
-    """bf16 mode's bias gradient: the staging pass that reads dY also leaves per-64-row column sums; finished by colsum they equal the
-    fp64 column sums to fp32 rounding, the stagings are bit-identical to the plain dual pass, and two runs agree bit for bit."""
-    from ytvln import ops
-    if not ops._FUSED_BIAS_GRAD:
-        pytest.skip("YTVLN_FUSED_BIAS_GRAD=0: every bias gradient goes through ytvln_colsum_f32")
-    g = torch.Generator().manual_seed(rows * 7 + cols)
-    x = (torch.randn(rows, cols + 8, generator=g) * 3 + 0.5).to(dev)[:, :cols]
-    (p0, _), (t0, _), done0 = ops._stage_bf16_dual(x, x.stride(0), rows, cols)
-    assert done0 is False
-    outs = []
-    for _ in range(2):
-        db = torch.full((cols,), float("nan"), device=dev)
-        (p, ldp), (t, ldt), done = ops._stage_bf16_dual(x, x.stride(0), rows, cols, colsum_out=db)
-        assert done is True
-        assert torch.equal(p.view(torch.int16), p0.view(torch.int16)) and torch.equal(t.view(torch.int16), t0.view(torch.int16))
-        outs.append(db)
-    assert torch.equal(outs[0], outs[1])
-    ref = x.double().sum(0)
-    scale = x.double().abs().sum(0)
-    assert bool(((outs[0].double() - ref).abs() <= 4e-7 * scale + 1e-30).all()), float(((outs[0].double() - ref).abs() / scale).max())
 
 
 def test_scatter_add_rows_sorted_is_exact_and_reproducible(dev, lib):

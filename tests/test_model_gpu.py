@@ -502,10 +502,14 @@ def test_loss_aware_heads_match_full_heads(dev, lib, all_options):
 
 
 def test_g2_full_model_bf16_projections(dev, lib):
-    """BASELINE config 5's arithmetic (bf16-staged projections and bf16-operand attention on v_mfma_f32_32x32x16_bf16, fp32 accumulation,
-    fp32 softmax / LayerNorm / losses / master weights)
-    against the same fp32 golden as test_g2.  Stated tolerance for this mode: each loss within 2e-2 relative (bf16 has an 8-bit
-    mantissa: 2^-9 = 2e-3 relative rounding per operand, averaged over the contractions and 24 layers), gradient norms within 5 %.
+    """BASELINE config 5's arithmetic -- the bf16-resident path: activations, activation gradients, logits and the weight copies are bf16 in
+    HBM, every projection and both attention products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; softmax / LayerNorm statistics /
+    loss reductions / master weights / AdamW stay fp32 -- against the same fp32 golden as test_g2.  Stated tolerance for this mode: each loss
+    within 2e-2 relative (bf16 has an 8-bit mantissa: 2^-9 = 2e-3 relative rounding per stored value, averaged over the contractions and 24
+    layers), gradient norms within 5 %.  One documented exception: the two pooler biases get 10 % -- with ONE item of 7 options the ranking
+    loss is shift-invariant across the options, so the per-option gradients of the pooled vector nearly cancel in the bias sum (|sum| is
+    about 1/40 of the sum of norms here) and a 1 % rounding of the inputs becomes a several-% change of that sum; the same parameters meet
+    the 5 % bar at N = 14 (test_g10) and the GEMM column-sum itself is checked directly in test_bf16_gpu.py.
     The fp32 path's 1e-4 bar does not apply -- and must NOT be met bit-for-bit, which guards against a silent fp32 fallback."""
     from ytvln import ops, synth
     g = gold("g2_full_n7.npz")
@@ -535,7 +539,8 @@ def test_g2_full_model_bf16_projections(dev, lib):
     for n, ref in zip(g["grad_names"].tolist(), g["grad_norms"]):
         got = float(pd[n].grad.double().norm())
         # (+1e-4: key-projection biases have a mathematically zero gradient -- softmax shift invariance -- so theirs is pure rounding noise)
-        if abs(got - ref) > 5e-2 * ref + 1e-4:
+        bar = 1e-1 if n.endswith("pooler.dense.bias") else 5e-2
+        if abs(got - ref) > bar * ref + 1e-4:
             bad.append((n, got, float(ref)))
     assert not bad, bad[:5]
 

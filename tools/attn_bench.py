@@ -16,14 +16,15 @@ only = os.environ.get("CASES")          # e.g. CASES="co" -> only the BertBiAtte
 if only:
     cases = [c for c in cases if c[0].startswith(only)]
 fwd_only = bool(os.environ.get("FWD_ONLY"))
-ops.set_matmul_precision(os.environ.get("PRECISION", "fp32"))      # PRECISION=bf16 -> bf16-operand kernels
+ops.set_matmul_precision(os.environ.get("PRECISION", "fp32"))      # PRECISION=bf16 -> the bf16-resident kernels (bf16 tensors in HBM)
+DT = torch.bfloat16 if os.environ.get("PRECISION") == "bf16" else torch.float32
 p = float(os.environ.get("PDROP", "0.1"))
 st = ops.DropoutState(dev)
 for name, h, d, Tq, Tk in cases:
     H = h * d
-    q, k, v = (torch.randn(N * T, H, device=dev) for T in (Tq, Tk, Tk))
+    q, k, v = (torch.randn(N * T, H, device=dev).to(DT) for T in (Tq, Tk, Tk))
     mask = torch.zeros(N, Tk, device=dev)
-    out, dout = torch.empty(N * Tq, H, device=dev), torch.randn(N * Tq, H, device=dev)
+    out, dout = torch.empty(N * Tq, H, device=dev, dtype=DT), torch.randn(N * Tq, H, device=dev).to(DT)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     sc = 1 / math.sqrt(d)
     def fwd(): return ops._attn_fwd(q, 0, H, k, 0, H, v, 0, H, mask, out, N, h, Tq, Tk, d, sc, p, st.tensor, 3)
@@ -47,8 +48,8 @@ for name, h, d, Tq, Tk in cases:
 if not only or only.startswith("co"):
     h, d, T, R = 8, 128, 80, RG
     Hb = h * d
-    q1, kv1 = torch.randn(N * R, Hb, device=dev), torch.randn(N * R, 2 * Hb, device=dev)
-    q2, kv2 = torch.randn(N * T, Hb, device=dev), torch.randn(N * T, 2 * Hb, device=dev)
+    q1, kv1 = torch.randn(N * R, Hb, device=dev).to(DT), torch.randn(N * R, 2 * Hb, device=dev).to(DT)
+    q2, kv2 = torch.randn(N * T, Hb, device=dev).to(DT), torch.randn(N * T, 2 * Hb, device=dev).to(DT)
     m1, m2 = torch.zeros(N, R, device=dev), torch.zeros(N, T, device=dev)
     for t in (q1, kv1, q2, kv2):
         t.requires_grad_(True)

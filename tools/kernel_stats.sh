@@ -1,16 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel trace of `python bench.py --graph off ...` (eager launches so every kernel is visible) -> per-kernel totals.
-# usage: tools/kernel_stats.sh <tag> [bench args...]   writes gpurun_out/<tag>_kernel_stats.csv and prints the top kernels
-export TMPDIR=/tmp; R=$PWD; TAG=$1; shift; mkdir -p $R/gpurun_out; cd /tmp; rm -rf /tmp/kst
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- python $R/bench.py --graph off --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-variants "$@" > /tmp/kst.log 2>&1
-tail -1 /tmp/kst.log | cut -c1-200
-F=$(ls /tmp/kst/*kernel_stats.csv | head -1)
-cp $F $R/gpurun_out/${TAG}_kernel_stats.csv
-python - $F <<'PYEOF'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/1e6:.1f} ms over the traced run (6 steps)")
-for r in rows[:int(__import__("os").environ.get("TOPN", "22"))]:
-    print(f'{float(r["TotalDurationNs"])/6e6:8.2f} ms/step {float(r["Percentage"]):5.1f}% calls/step {int(r["Calls"])/6:7.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {r["Name"][:90]}')
-PYEOF
+# rocprofv3 kernel trace + stats of a bench.py command -> gpurun_out/<name>_kernel_stats.csv   usage: tools/kernel_stats.sh <name> <bench args...>
+name=$1; shift
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $out/prof_$name
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -o $name -- python $GRAFT_REPO_ROOT/bench.py "$@" > $out/${name}_bench.json 2> $out/${name}_bench.err
+f=$(find $out/prof_$name -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $out/${name}_kernel_stats.csv
+rm -rf $out/prof_$name
+head -c 400 $out/${name}_bench.json; echo

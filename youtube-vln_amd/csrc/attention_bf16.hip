@@ -508,8 +508,11 @@ template <int DP, bool DROP>
 __global__ __launch_bounds__(64, 2) void battn_fwd_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_fwd_body<DP, DROP>(a, bx, h, n))); }
 template <int DP, bool DROP>
 __global__ __launch_bounds__(64, 2) void battn_bwd_dq_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_bwd_dq_body<DP, DROP>(a, bx, h, n))); }
+#ifndef BATTN_DKV_WPS
+#define BATTN_DKV_WPS 1          // d = 128: 512 registers and no spills beat two spilling waves per SIMD (img self bwd 2485 -> 2393 us, co pair bwd 1875 -> 1723 us at cfg 5)
+#endif
 template <int DP, bool DROP>
-__global__ __launch_bounds__(64, 2) void battn_bwd_dkv_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_bwd_dkv_body<DP, DROP>(a, bx, h, n))); }
+__global__ __launch_bounds__(64, DP == 128 ? BATTN_DKV_WPS : 2) void battn_bwd_dkv_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_bwd_dkv_body<DP, DROP>(a, bx, h, n))); }
 #undef YT_BATTN_DECODE
 
 static int bcheck(const char* who, const BAttnArgs& a) {

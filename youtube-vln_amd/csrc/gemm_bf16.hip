@@ -12,8 +12,9 @@
 // rounds once (RNE) into a bf16 or fp32 C.
 //
 // Structure (as gemm_dma_kernel of gemm.hip): workgroup tile 256x256 (8 waves of 64x128, one workgroup per CU) or 128x128 (8 waves of 32x64,
-// two per CU), 64-deep k-tiles, both operand tiles delivered by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces, no VGPR staging) into a 2-stage
-// ring, one barrier per k-tile with the next tile in flight under the matrix instructions.  LDS images (the DMA writes lane-linear pieces, so
+// two per CU), 64-deep k-tiles, both operand tiles delivered by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces, no VGPR staging), A into a
+// 3-slot ring (two k-tiles ahead), B into a 2-slot ring (one ahead) = all 160 KB of LDS; the main loop is a two-group ping-pong of load and
+// matrix phases (four barriers per k-tile, counted vmcnt, see the kernel).  LDS images (the DMA writes lane-linear pieces, so
 // the layout is chosen through the per-lane SOURCE address):
 //   contraction-contiguous operand  S[m][64]   128-byte rows, 16-byte granule g stored at g ^ ((m >> 1) & 7): conflict-free ds_read_b128
 //   k-major operand                 T[k][BMN]  granule g of row k stored at g ^ (4 (k & 3)): the four k rows of a transposing read land on four
@@ -265,9 +266,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
     using TB = BfTile<BN, B_KC, NW>;
     constexpr int WM = NW / 2;                          // waves along m (x 2 along n)
     constexpr int TM = BM / WM / 32, TN = BN / 64;
-    constexpr int SA = BM * KT * 2, SB = BN * KT * 2, STAGE = SA + SB;      // bytes
-    constexpr int NPT = TA::NI + TB::NI;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];           // ONE shared object (a second one de-pipelines the DMA)
+    constexpr int SA = BM * KT * 2, SB = BN * KT * 2;                       // bytes per operand tile
+    // LDS rings: THREE slots for A, TWO for B -- exactly the 160 KB of a CU for one 256x256 workgroup (two 128x128 ones).  A (the activation /
+    // gradient matrix, streamed from HBM once) is fetched TWO k-tiles ahead, B (the weight panel every workgroup of a tile column re-reads: L2)
+    // one; with two slots each the next tile had a single k-tile of matrix time (~1 us) to arrive and the wait in front of the barrier drained it.
+    constexpr int NSA = 3, NSB = 2;
+    __shared__ __attribute__((aligned(16))) char smem[NSA * SA + NSB * SB];  // ONE shared object (a second one de-pipelines the DMA)
+    char* const ringA = smem;
+    char* const ringB = smem + NSA * SA;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -305,64 +311,126 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
-    auto issue = [&](int kt) {
-        char* As = smem + (kt & 1) * STAGE;
-        char* Bs = As + SA;
+    int slotA_in = 0, slotB_in = 0;          // ring slots the next issues fill
+    auto issueA = [&](int kt) {
+        char* As = ringA + slotA_in * SA;
+        slotA_in = slotA_in + 1 == NSA ? 0 : slotA_in + 1;
         if (kt < nfull) {
 #pragma unroll
             for (int i = 0; i < TA::NI; ++i) {
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 1024), 16, 0, 0);
                 pa[i] += sa;
             }
-#pragma unroll
-            for (int i = 0; i < TB::NI; ++i) {
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 1024), 16, 0, 0);
-                pb[i] += sb;
-            }
         } else {          // rare: the tile crosses K -- the same pieces through registers, zero past the end (the waits of the loop cover the ds_writes)
             const int k0 = kbeg + kt * KT;
 #pragma unroll
             for (int i = 0; i < TA::NI; ++i)
                 *reinterpret_cast<uint4*>(As + (wave * TA::NI + i) * 1024 + 16 * lane) = TA::tail(g.A, g.lda, g.mnA, m0, k0, wave * TA::NI + i, lane, g.kvalidA);
+        }
+    };
+    auto issueB = [&](int kt) {
+        char* Bs = ringB + slotB_in * SB;
+        slotB_in = slotB_in + 1 == NSB ? 0 : slotB_in + 1;
+        if (kt < nfull) {
+#pragma unroll
+            for (int i = 0; i < TB::NI; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 1024), 16, 0, 0);
+                pb[i] += sb;
+            }
+        } else {
+            const int k0 = kbeg + kt * KT;
 #pragma unroll
             for (int i = 0; i < TB::NI; ++i)
                 *reinterpret_cast<uint4*>(Bs + (wave * TB::NI + i) * 1024 + 16 * lane) = TB::tail(g.B, g.ldb, g.mnB, n0, k0, wave * TB::NI + i, lane, g.kvalidB);
         }
     };
 
-    if (nk > 0) issue(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // my pieces of tile kt have landed (DMA: vmcnt; register-staged tail: lgkmcnt); after the barrier everybody's have, and everybody is done
-        // reading the slot tile kt+1 is about to overwrite
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue(kt + 1);
-        const char* As = smem + (kt & 1) * STAGE;
-        const char* Bs = As + SA;
+    // Main loop = a two-group PING-PONG (guide: 8-phase GEMM template).  The 8 waves are two groups of four (one wave per SIMD each); a k-tile
+    // is four phases, each closed by a workgroup barrier:
+    //     L01  read the fragments of matrix steps s = 0, 1 from LDS; issue the DMA of B(kt+1)            M01  16 (TM TN x 2) matrix instructions
+    //     L23  read s = 2, 3; issue the DMA of A(kt+2); wait for this wave's pieces of tile kt+1          M23  16 matrix instructions
+    // and group 1 runs ONE barrier behind group 0 (it takes an extra barrier before the loop, group 0 one after it), so whenever one wave of a
+    // SIMD is in a load phase -- LDS-DMA issue (~100 cycles a piece), 12 LDS reads, waits -- the other one is in a matrix phase: the two waves of
+    // a SIMD no longer stall on the same thing at the same time (in lock-step the matrix pipe idled through every DMA-issue / read phase).
+    // Hazards (slot = interval between two barrier releases; group g runs phase p in slot p + g):
+    //   * a ring slot is refilled at least one full slot after the other group's last read of it (A: 3 slots, refilled in L23(kt) with tile kt+2,
+    //     last read in L23(kt-1); B: 2 slots, refilled in L01(kt) with tile kt+1, last read in L23(kt-1)), and every read is retired (lgkmcnt(0))
+    //     before the barrier that closes its phase;
+    //   * every wave waits for its own pieces of tile kt+1 in L23(kt); group 0 first reads that tile two barriers later, group 1 three.
+    //   vector memory retires in order and B(kt+1) is issued before A(kt+2): "at most NI_A outstanding" = tile kt+1 complete, A(kt+2) in flight.
+    const int grp = wave >> 2;                                   // waves 0-3 / 4-7 (wave-uniform SGPR)
+    bf16x8 fra[2][TM], frb[2][TN];
+    auto read_frags = [&](const char* __restrict__ As, const char* __restrict__ Bs, int s0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 a[TM], b[TN];
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = fa.get(As, i, half, s);
-            if constexpr (!A_KC) {
-                if (do_asum) {          // wave-uniform: first tile column, first wave column
+            for (int i = 0; i < TM; ++i) fra[u][i] = fa.get(As, i, half, s0 + u);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) frb[u][j] = fb.get(Bs, j, half, s0 + u);
+        }
+    };
+    auto matrix_phase = [&]() __attribute__((always_inline)) {
+        if constexpr (!A_KC) {
+            if (do_asum) {          // wave-uniform: first tile column, first wave column (row sums of A: the bias gradient)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         float t = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) t += (float)a[i][e];
+                        for (int e = 0; e < 8; ++e) t += (float)fra[u][i][e];
                         asum[i] += t;
                     }
-                }
             }
+        }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = fb.get(Bs, j, half, s);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[u][i], frb[u][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (nk > 0) { issueA(0); issueB(0); }
+    if (nk > 1) issueA(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TA::NI) : "memory");          // A(0), B(0) landed; A(1) may be in flight
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                  // the stagger: group 1 one slot behind from here on
+    int slotA_out = 0, slotB_out = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* As = ringA + slotA_out * SA;
+        const char* Bs = ringB + slotB_out * SB;
+        slotA_out = slotA_out + 1 == NSA ? 0 : slotA_out + 1;
+        slotB_out = slotB_out + 1 == NSB ? 0 : slotB_out + 1;
+        // ---- L01
+        read_frags(As, Bs, 0);
+        if (kt + 1 < nk) issueB(kt + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- M01
+        matrix_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- L23
+        read_frags(As, Bs, 2);
+        if (kt + 2 < nk) {
+            issueA(kt + 2);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TA::NI) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- M23
+        matrix_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                  // (every wave executes the same number of barriers)
     if constexpr (!A_KC) {
         if (do_asum) {
 #pragma unroll

@@ -19,10 +19,15 @@ __device__ __forceinline__ MS ms_push(MS a, float x) {
     if (x <= a.m) return {a.m, a.s + expf(x - a.m)};
     return {x, a.s * expf(a.m - x) + 1.0f};
 }
+// logits are fp32, or bf16 on the bf16-resident path (BASELINE configs[4]: the decoders write bf16 logits, the gradient goes back as bf16)
+__device__ __forceinline__ float lget(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float lget(const uint16_t* p, int64_t i) { return __uint_as_float((uint32_t)p[i] << 16); }
+
 // block-wide (256 threads) log-sum-exp of a row; result valid in all threads
-__device__ __forceinline__ float block_lse(const float* __restrict__ row, int V, float* sh /* [8] */) {
+template <typename LT>
+__device__ __forceinline__ float block_lse(const LT* __restrict__ row, int V, float* sh /* [8] */) {
     MS a = {-INFINITY, 0.f};
-    for (int c = threadIdx.x; c < V; c += 256) a = ms_push(a, row[c]);
+    for (int c = threadIdx.x; c < V; c += 256) a = ms_push(a, lget(row, c));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         MS b = {__shfl_xor(a.m, o, 64), __shfl_xor(a.s, o, 64)};
@@ -45,17 +50,18 @@ __device__ __forceinline__ float block_sum(float v, float* sh /* [4] */) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
+template <typename LT>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const LT* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
                                                      int64_t ignore, float* __restrict__ row_lse, float* __restrict__ row_loss, int V) {
     __shared__ float sh[8];
     const int row = blockIdx.x;
     const int64_t t = target[row];
-    const float* x = logits + (int64_t)row * ld;
+    const LT* x = logits + (int64_t)row * ld;
     const float lse = block_lse(x, V, sh);
     if (threadIdx.x == 0) {
         row_lse[row] = lse;
         // a target outside [0, V) that is not the ignore index (torch's kernel asserts): never read out of bounds, poison the loss
-        row_loss[row] = (t == ignore) ? 0.f : (t >= 0 && t < V) ? lse - x[t] : NAN;
+        row_loss[row] = (t == ignore) ? 0.f : (t >= 0 && t < V) ? lse - lget(x, t) : NAN;
     }
 }
 
@@ -70,13 +76,13 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
     if (threadIdx.x == 0) { out[0] = S / C; out[1] = C; }
 }
 
-// DT = float: the fp32 gradient (columns [0, V)).  DT = uint16_t: the bf16-resident path -- the gradient rounded to bf16 (RNE) AND zeros in the
-// padding columns [V, ldd), so that the buffer can feed the bf16 GEMMs as a zero-padded operand (YTVLN_GEMM_A_ZERO_PADDED) as it stands.
+// DT = float: fp32 logits, fp32 gradient (columns [0, V)).  DT = uint16_t: the bf16-resident path -- bf16 logits, the gradient rounded to bf16
+// (RNE) AND zeros in the padding columns [V, ldd), so that the buffer feeds the bf16 GEMMs as a zero-padded operand (YTVLN_GEMM_A_ZERO_PADDED).
 __device__ __forceinline__ void grad_store(float* d, int c, float v) { d[c] = v; }
 __device__ __forceinline__ void grad_store(uint16_t* d, int c, float v) { d[c] = __builtin_bit_cast(uint16_t, (__bf16)v); }
 
 template <typename DT>
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const DT* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
                                                      int64_t ignore, const float* __restrict__ row_lse, const float* __restrict__ out,
                                                      const float* __restrict__ gout, DT* __restrict__ dl, int64_t ldd, int V) {
     const int row = blockIdx.x;
@@ -88,12 +94,13 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
         return;
     }
     const float coef = gout[0] / out[1], lse = row_lse[row];
-    const float* x = logits + (int64_t)row * ld;
-    for (int c = threadIdx.x; c < V; c += 256) grad_store(d, c, (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * coef);
+    const DT* x = logits + (int64_t)row * ld;
+    for (int c = threadIdx.x; c < V; c += 256) grad_store(d, c, (expf(lget(x, c) - lse) - (c == t ? 1.f : 0.f)) * coef);
     for (int c = V + threadIdx.x; c < Vz; c += 256) grad_store(d, c, 0.f);
 }
 
-__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ pred, int64_t ld, const float* __restrict__ tgt, int64_t ldt,
+template <typename LT>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const LT* __restrict__ pred, int64_t ld, const float* __restrict__ tgt, int64_t ldt,
                                                      const int64_t* __restrict__ mask, float* __restrict__ row_lse,
                                                      float* __restrict__ row_loss, int C) {
     __shared__ float sh[8];
@@ -102,13 +109,13 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ p
         if (threadIdx.x == 0) { row_lse[row] = 0.f; row_loss[row] = 0.f; }
         return;
     }
-    const float* x = pred + (int64_t)row * ld;
+    const LT* x = pred + (int64_t)row * ld;
     const float* t = tgt + (int64_t)row * ldt;
     const float lse = block_lse(x, C, sh);
     float acc = 0.f;   // sum_c t * (log t - (x - lse)), 0 where t == 0 (xlogy semantics of F.kl_div)
     for (int c = threadIdx.x; c < C; c += 256) {
         const float tv = t[c];
-        if (tv > 0.f) acc += tv * (logf(tv) - (x[c] - lse));
+        if (tv > 0.f) acc += tv * (logf(tv) - (lget(x, c) - lse));
     }
     const float tot = block_sum(acc, sh) * (float)mask[row];
     if (threadIdx.x == 0) { row_lse[row] = lse; row_loss[row] = tot; }
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void kl_finalize_kernel(const float* __restric
 }
 
 template <typename DT>
-__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ pred, int64_t ld, const float* __restrict__ tgt, int64_t ldt,
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const DT* __restrict__ pred, int64_t ld, const float* __restrict__ tgt, int64_t ldt,
                                                      const int64_t* __restrict__ mask, const float* __restrict__ row_lse,
                                                      const float* __restrict__ out, const float* __restrict__ gout,
                                                      DT* __restrict__ dp, int64_t ldd, int C) {
@@ -138,13 +145,13 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ p
         for (int c = threadIdx.x; c < Cz; c += 256) grad_store(d, c, 0.f);
         return;
     }
-    const float* x = pred + (int64_t)row * ld;
+    const DT* x = pred + (int64_t)row * ld;
     const float* t = tgt + (int64_t)row * ldt;
     float ts = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) ts += t[c];
     const float tsum = block_sum(ts, sh);
     const float coef = gout[0] / out[1] * (float)mask[row], lse = row_lse[row];
-    for (int c = threadIdx.x; c < C; c += 256) grad_store(d, c, coef * (expf(x[c] - lse) * tsum - t[c]));
+    for (int c = threadIdx.x; c < C; c += 256) grad_store(d, c, coef * (expf(lget(x, c) - lse) * tsum - t[c]));
     for (int c = C + threadIdx.x; c < Cz; c += 256) grad_store(d, c, 0.f);
 }
 
@@ -181,9 +188,19 @@ extern "C" int ytvln_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* 
                                 float* row_loss, float* out, int M, int V, void* stream) {
     YT_REQUIRE(logits && target && row_lse && row_loss && out && M > 0 && V > 0 && ld >= V, "ce_fwd: bad argument");
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(256), 0, s, logits, ld, target, ignore_index, row_lse, row_loss, V);
+    hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(M), dim3(256), 0, s, logits, ld, target, ignore_index, row_lse, row_loss, V);
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, row_loss, target, ignore_index, M, out);
     YT_LAUNCH_CHECK("ce_fwd");
+    return 0;
+}
+
+extern "C" int ytvln_ce_fwd_bf16(const uint16_t* logits, int64_t ld, const int64_t* target, int64_t ignore_index, float* row_lse,
+                                 float* row_loss, float* out, int M, int V, void* stream) {
+    YT_REQUIRE(logits && target && row_lse && row_loss && out && M > 0 && V > 0 && ld >= V, "ce_fwd_bf16: bad argument");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(ce_fwd_kernel<uint16_t>, dim3(M), dim3(256), 0, s, logits, ld, target, ignore_index, row_lse, row_loss, V);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, row_loss, target, ignore_index, M, out);
+    YT_LAUNCH_CHECK("ce_fwd_bf16");
     return 0;
 }
 
@@ -196,7 +213,7 @@ extern "C" int ytvln_ce_bwd_f32(const float* logits, int64_t ld, const int64_t* 
     return 0;
 }
 
-extern "C" int ytvln_ce_bwd_bf16(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
+extern "C" int ytvln_ce_bwd_bf16(const uint16_t* logits, int64_t ld, const int64_t* target, int64_t ignore_index, const float* row_lse,
                                  const float* out, const float* gout, uint16_t* dlogits, int64_t ldd, int M, int V, void* stream) {
     YT_REQUIRE(logits && target && row_lse && out && gout && dlogits && M > 0 && V > 0 && ldd >= V, "ce_bwd_bf16: bad argument");
     hipLaunchKernelGGL(ce_bwd_kernel<uint16_t>, dim3(M), dim3(256), 0, as_stream(stream), logits, ld, target, ignore_index, row_lse, out, gout,
@@ -209,9 +226,19 @@ extern "C" int ytvln_kl_fwd_f32(const float* pred, int64_t ld, const float* targ
                                 float* row_loss, float* out, int M, int C, void* stream) {
     YT_REQUIRE(pred && target && mask && row_lse && row_loss && out && M > 0 && C > 0, "kl_fwd: bad argument");
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(kl_fwd_kernel, dim3(M), dim3(256), 0, s, pred, ld, target, ldt, mask, row_lse, row_loss, C);
+    hipLaunchKernelGGL(kl_fwd_kernel<float>, dim3(M), dim3(256), 0, s, pred, ld, target, ldt, mask, row_lse, row_loss, C);
     hipLaunchKernelGGL(kl_finalize_kernel, dim3(1), dim3(256), 0, s, row_loss, mask, M, out);
     YT_LAUNCH_CHECK("kl_fwd");
+    return 0;
+}
+
+extern "C" int ytvln_kl_fwd_bf16(const uint16_t* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, float* row_lse,
+                                 float* row_loss, float* out, int M, int C, void* stream) {
+    YT_REQUIRE(pred && target && mask && row_lse && row_loss && out && M > 0 && C > 0, "kl_fwd_bf16: bad argument");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(kl_fwd_kernel<uint16_t>, dim3(M), dim3(256), 0, s, pred, ld, target, ldt, mask, row_lse, row_loss, C);
+    hipLaunchKernelGGL(kl_finalize_kernel, dim3(1), dim3(256), 0, s, row_loss, mask, M, out);
+    YT_LAUNCH_CHECK("kl_fwd_bf16");
     return 0;
 }
 
@@ -225,7 +252,7 @@ extern "C" int ytvln_kl_bwd_f32(const float* pred, int64_t ld, const float* targ
     return 0;
 }
 
-extern "C" int ytvln_kl_bwd_bf16(const float* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, const float* row_lse,
+extern "C" int ytvln_kl_bwd_bf16(const uint16_t* pred, int64_t ld, const float* target, int64_t ldt, const int64_t* mask, const float* row_lse,
                                  const float* out, const float* gout, uint16_t* dpred, int64_t ldd, int M, int C, void* stream) {
     YT_REQUIRE(pred && target && mask && row_lse && out && gout && dpred && M > 0 && C > 0 && ldd >= C, "kl_bwd_bf16: bad argument");
     hipLaunchKernelGGL(kl_bwd_kernel<uint16_t>, dim3(M), dim3(256), 0, as_stream(stream), pred, ld, target, ldt, mask, row_lse, out, gout, dpred,

@@ -227,6 +227,196 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
         out[i] = (red[i] + red[2 * a.H + i]) + (red[4 * a.H + i] + red[6 * a.H + i]);
 }
 
+// ---- bf16 rows, 16 bytes per lane -----------------------------------------------------------------------------------------------------
+// The plain (dropout ->) residual -> LayerNorm of the bf16-resident path moves HALF the bytes of the fp32 kernel, so per byte everything that is
+// not a memory access weighs twice: these forms take 8 elements (one 16-byte access) per lane and vector, and draw the hidden-state dropout
+// mask from ONE Philox call per 8 elements (16 bits per element: keep iff bits16 >= round(p * 65536); P(drop) = 0.1000061 for p = 0.1).
+// Forward and backward regenerate the same mask from (seed, counter, site, row, vector index); the fp32 kernels keep their 32-bit draws.
+struct f8 { float v[8]; };
+__device__ __forceinline__ f8 ld8(const bf16_t* p, int64_t c8) {
+    const uint4 u = reinterpret_cast<const uint4*>(p)[c8];
+    f8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st8(bf16_t* p, int64_t c8, const f8& r) {
+    reinterpret_cast<uint4*>(p)[c8] = make_uint4(bfbits(r.v[0]) | (bfbits(r.v[1]) << 16), bfbits(r.v[2]) | (bfbits(r.v[3]) << 16),
+                                                 bfbits(r.v[4]) | (bfbits(r.v[5]) << 16), bfbits(r.v[6]) | (bfbits(r.v[7]) << 16));
+}
+__device__ __forceinline__ f8 ldg8(const float* p, int c8) {
+    const float4 a = reinterpret_cast<const float4*>(p)[2 * c8], b = reinterpret_cast<const float4*>(p)[2 * c8 + 1];
+    f8 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ uint32_t drop_threshold16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ void keep8(f8& r, const u32x4 b, uint32_t thr16, float ik) {          // element e keeps iff its 16 random bits >= thr16
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t bits = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+        r.v[e] = bits >= thr16 ? r.v[e] * ik : 0.f;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const LnArgs a) {
+    const bf16_t* const xin = reinterpret_cast<const bf16_t*>(a.x);
+    const bf16_t* const rin = reinterpret_cast<const bf16_t*>(a.res);
+    bf16_t* const yout = reinterpret_cast<bf16_t*>(a.y);
+    bf16_t* const sout = reinterpret_cast<bf16_t*>(a.s_out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H8 = a.H >> 3;
+    const float invH = 1.0f / (float)a.H;
+    const bool pre = a.p_pre > 0.f, post = a.p_post > 0.f;
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr_pre = 0, thr_post = 0;
+    float ik_pre = 1.f, ik_post = 1.f;
+    if (pre || post) {
+        key = make_drop_key(a.rng, a.site);
+        thr_pre = drop_threshold16(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
+        thr_post = drop_threshold16(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
+    }
+    f8 gm[NV], bt[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (lane + 64 * j < H8) { gm[j] = ldg8(a.gamma, lane + 64 * j); bt[j] = ldg8(a.beta, lane + 64 * j); }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+        f8 s[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c8 = lane + 64 * j;
+            if (c8 < H8) {
+                s[j] = ld8(xin + row * a.H, c8);
+                if (pre) keep8(s[j], drop_bits(key, (uint64_t)row * H8 + c8), thr_pre, ik_pre);
+                if (rin) {
+                    const f8 r = ld8(rin + row * a.H, c8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[j].v[e] += r.v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) sum += s[j].v[e] + s[j].v[e + 1];
+            }
+        }
+        const float mu = wave_sum(sum) * invH;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (lane + 64 * j < H8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dd = s[j].v[e] - mu; sq += dd * dd; }
+            }
+        const float var = wave_sum(sq) * invH;
+        const float rs = 1.0f / sqrtf(var + a.eps);
+        if (lane == 0) {
+            if (a.mean) a.mean[row] = mu;
+            if (a.rstd) a.rstd[row] = rs;
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c8 = lane + 64 * j;
+            if (c8 < H8) {
+                if (sout) st8(sout + row * a.H, c8, s[j]);
+                f8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = gm[j].v[e] * ((s[j].v[e] - mu) * rs) + bt[j].v[e];
+                if (post) keep8(o, drop_bits(key, (uint64_t)row * H8 + c8), thr_post, ik_post);
+                st8(yout + row * a.H, c8, o);
+            }
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const LnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2][H]
+    const bf16_t* const dyin = reinterpret_cast<const bf16_t*>(a.dy);
+    const bf16_t* const sin = reinterpret_cast<const bf16_t*>(a.s);
+    bf16_t* const dsout = reinterpret_cast<bf16_t*>(a.ds);
+    bf16_t* const dxout = reinterpret_cast<bf16_t*>(a.dx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H8 = a.H >> 3;
+    const float invH = 1.0f / (float)a.H;
+    const bool pre = a.p_pre > 0.f, post = a.p_post > 0.f;
+    DropKey key = {0, 0, 0, 0};
+    uint32_t thr_pre = 0, thr_post = 0;
+    float ik_pre = 1.f, ik_post = 1.f;
+    if (pre || post) {
+        key = make_drop_key(a.rng, a.site);
+        thr_pre = drop_threshold16(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
+        thr_post = drop_threshold16(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
+    }
+    f8 dg[NV], db[NV], gm[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[j].v[e] = 0.f; db[j].v[e] = 0.f; gm[j].v[e] = 0.f; }
+        if (lane + 64 * j < H8) gm[j] = ldg8(a.gamma, lane + 64 * j);
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+    const int64_t r1 = min(r0 + a.rows_per_block, a.rows);
+    for (int64_t row = r0 + wave; row < r1; row += 4) {
+        const float mu = a.mean[row], rs = a.rstd[row];
+        f8 g[NV], xh[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c8 = lane + 64 * j;
+            if (c8 < H8) {
+                f8 d = ld8(dyin + row * a.H, c8);
+                if (post) keep8(d, drop_bits(key, (uint64_t)row * H8 + c8), thr_post, ik_post);
+                const f8 sv = ld8(sin + row * a.H, c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[j].v[e] = (sv.v[e] - mu) * rs;
+                    dg[j].v[e] += d.v[e] * xh[j].v[e];
+                    db[j].v[e] += d.v[e];
+                    g[j].v[e] = d.v[e] * gm[j].v[e];
+                    c1 += g[j].v[e];
+                    c2 += g[j].v[e] * xh[j].v[e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) * invH;
+        c2 = wave_sum(c2) * invH;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c8 = lane + 64 * j;
+            if (c8 < H8) {
+                f8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = rs * (g[j].v[e] - c1 - xh[j].v[e] * c2);
+                if (dsout) st8(dsout + row * a.H, c8, o);
+                if (a.ds_f32) {
+                    reinterpret_cast<float4*>(a.ds_f32 + row * a.H)[2 * c8] = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
+                    reinterpret_cast<float4*>(a.ds_f32 + row * a.H)[2 * c8 + 1] = make_float4(o.v[4], o.v[5], o.v[6], o.v[7]);
+                }
+                if (pre && dxout) {
+                    keep8(o, drop_bits(key, (uint64_t)row * H8 + c8), thr_pre, ik_pre);
+                    st8(dxout + row * a.H, c8, o);
+                }
+            }
+        }
+    }
+    float* mine = red + wave * 2 * a.H;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c8 = lane + 64 * j;
+        if (c8 < H8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mine[8 * c8 + e] = dg[j].v[e]; mine[a.H + 8 * c8 + e] = db[j].v[e]; }
+        }
+    }
+    __syncthreads();
+    float* out = a.partial + (int64_t)blockIdx.x * 2 * a.H;
+    for (int i = threadIdx.x; i < 2 * a.H; i += 256)
+        out[i] = (red[i] + red[2 * a.H + i]) + (red[4 * a.H + i] + red[6 * a.H + i]);
+}
+
 // ---- column reductions --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
                                                      float* __restrict__ out, int64_t ldo, int rpb) {
@@ -605,7 +795,16 @@ extern "C" int ytvln_ln_fwd_bf16(const uint16_t* x, const uint16_t* res, const f
     LnArgs a = {};
     a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.s_out = s_out; a.mean = mean; a.rstd = rstd;
     a.rows = rows; a.H = H; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
-    launch_ln<LN_PLAIN, bf16_t, bf16_t>(a, as_stream(stream));
+    if (H % 8 == 0 && al16(x) && al16(y) && (!res || al16(res)) && (!s_out || al16(s_out))) {          // 16 bytes per lane
+        const int nv = (int)cdiv(H / 8, 64);
+        const int grid = (int)std::min<int64_t>(cdiv(rows, 4), 8192);
+        hipStream_t st = as_stream(stream);
+        if (nv <= 1) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<1>), dim3(grid), dim3(256), 0, st, a);
+        else if (nv <= 2) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<2>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<4>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        launch_ln<LN_PLAIN, bf16_t, bf16_t>(a, as_stream(stream));
+    }
     YT_LAUNCH_CHECK("ln_fwd_bf16");
     return 0;
 }
@@ -662,6 +861,14 @@ extern "C" int ytvln_ln_bwd_bf16(const uint16_t* dy, const uint16_t* s, const fl
     const int nv = (int)cdiv(H / 4, 64);
     const size_t lds = (size_t)8 * H * sizeof(float);
     hipStream_t st = as_stream(stream);
+    if (H % 8 == 0 && al16(dy) && al16(s) && (!ds || al16(ds)) && (!dx || al16(dx))) {          // 16 bytes per lane (and the 16-bit dropout draws of ln_fwd_bf16x8_kernel)
+        const int nv8 = (int)cdiv(H / 8, 64);
+        if (nv8 <= 1) hipLaunchKernelGGL((ln_bwd_bf16x8_kernel<1>), dim3(nb), dim3(256), lds, st, a);
+        else if (nv8 <= 2) hipLaunchKernelGGL((ln_bwd_bf16x8_kernel<2>), dim3(nb), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((ln_bwd_bf16x8_kernel<4>), dim3(nb), dim3(256), lds, st, a);
+        YT_LAUNCH_CHECK("ln_bwd_bf16");
+        return 0;
+    }
     if (nv <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1, bf16_t>), dim3(nb), dim3(256), lds, st, a);
     else if (nv <= 2) hipLaunchKernelGGL((ln_bwd_kernel<2, bf16_t>), dim3(nb), dim3(256), lds, st, a);
     else if (nv <= 4) hipLaunchKernelGGL((ln_bwd_kernel<4, bf16_t>), dim3(nb), dim3(256), lds, st, a);

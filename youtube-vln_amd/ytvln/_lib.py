@@ -59,7 +59,9 @@ SIGNATURES = {
     "ytvln_text_embed_fwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, P, I64, P],
     "ytvln_image_embed_fwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, I64, P],
     "ytvln_act_bwd_bf16": [P, P, P, I64, I32, P],
+    "ytvln_ce_fwd_bf16": [P, I64, P, I64, P, P, P, I32, I32, P],
     "ytvln_ce_bwd_bf16": [P, I64, P, I64, P, P, P, P, I64, I32, I32, P],
+    "ytvln_kl_fwd_bf16": [P, I64, P, I64, P, P, P, P, I32, I32, P],
     "ytvln_kl_bwd_bf16": [P, I64, P, I64, P, P, P, P, P, I64, I32, I32, P],
     "ytvln_adamw_f32_bf16copy": [P, P, P, P, P, P, I32, P, F32, P],
     "ytvln_ln_fwd_f32": [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, I64, P],

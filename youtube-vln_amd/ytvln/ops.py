@@ -56,6 +56,18 @@ def _rows2d(x: Tensor, name: str) -> Tuple[Tensor, int, int, int]:
     return x, x.numel() // max(K, 1), K, K
 
 
+def _rows2d_any(x: Tensor) -> Tuple[Tensor, int, int, int]:
+    """_rows2d without the fp32 check (bf16 logits of the bf16-resident path; rows may carry a padded leading dimension)."""
+    if not x.is_cuda:
+        raise RuntimeError("ytvln.ops: tensor must live on the GPU")
+    K = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K:
+        return x, x.shape[0], K, x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x, x.numel() // max(K, 1), K, K
+
+
 def _i64(t: Tensor, name: str) -> Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"ytvln.ops: `{name}` must live on the GPU")
@@ -472,7 +484,7 @@ def _wants_bf16(x: Tensor, weight: Tensor) -> bool:
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None, out_fp32: bool = False) -> Tensor:
-    """`out_fp32` only matters on the bf16-resident path: the output leaves the path as fp32 (logits for the loss kernels, pooled vectors)."""
+    """`out_fp32` only matters on the bf16-resident path: the output leaves the path as fp32 (the pooled vectors and the small heads on them)."""
     if _wants_bf16(x, weight):
         return LinearBf16Fn.apply(x, weight, bias, act, False, out_fp32)
     return LinearFn.apply(x, weight, bias, act)
@@ -683,7 +695,7 @@ def _alloc_rows_bf16(M: int, N: int, device):
 
 class LinearBf16Fn(torch.autograd.Function):
     """y = act(x W^T + b) on the bf16-resident path (same contract as LinearFn, incl. `passthrough`).  x: bf16 hidden states (or fp32 network
-    inputs, cast once); W: the bf16 copy of the fp32 master weight; y: bf16, or fp32 when `out_fp32` (logits, pooled vectors).  Backward:
+    inputs, cast once); W: the bf16 copy of the fp32 master weight; y: bf16, or fp32 when `out_fp32` (pooled vectors).  Backward:
     dX = dY W and dW = dY^T X read dY, W and X as they lie in HBM (k-major operands through the transposing LDS read); dW and db are fp32
     and go straight into the gradient arena; db rides on the dW launch."""
 
@@ -1326,16 +1338,18 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
         ctx.set_materialize_grads(False)
-        lg, M, V, ld = _rows2d(logits, "logits")
+        bf = logits.dtype == _BF16             # bf16-resident path: bf16 logits in, bf16 gradient out (same kernels, 2-byte loads/stores)
+        lg, M, V, ld = _rows2d_any(logits) if bf else _rows2d(logits, "logits")
         tg = _i64(target, "target").reshape(-1)
         assert tg.numel() == M, (tg.shape, M)
         dev = lg.device
         row_lse = torch.empty(M, dtype=torch.float32, device=dev)
         row_loss = torch.empty(M, dtype=torch.float32, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)
-        call("ytvln_ce_fwd_f32", _ptr(lg), ld, _ptr(tg), int(ignore_index), _ptr(row_lse), _ptr(row_loss), _ptr(out), M, V, _stream())
+        call("ytvln_ce_fwd_bf16" if bf else "ytvln_ce_fwd_f32", lg.data_ptr(), ld, _ptr(tg), int(ignore_index), _ptr(row_lse), _ptr(row_loss),
+             _ptr(out), M, V, _stream())
         ctx.meta = (M, V, ld, int(ignore_index), logits.shape)
-        ctx.bf16_grad = _MATMUL_PRECISION == "bf16" and M * V >= (1 << 16)      # bf16-resident path: the (large) logit gradient leaves as bf16
+        ctx.bf16_grad = bf
         ctx.save_for_backward(lg, tg, row_lse, out)
         return out[0]
 
@@ -1348,7 +1362,7 @@ class CrossEntropyFn(torch.autograd.Function):
         g = g.reshape(1).contiguous().float()
         if ctx.bf16_grad:          # rounded once, zero padding written by the kernel: feeds ytvln_gemm_bf16 as it stands
             dl, ldd = _alloc_rows_bf16(M, V, lg.device)
-            call("ytvln_ce_bwd_bf16", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), dl.data_ptr(), ldd, M, V, _stream())
+            call("ytvln_ce_bwd_bf16", lg.data_ptr(), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), dl.data_ptr(), ldd, M, V, _stream())
             return _view_rows_as(dl, ldd, shape), None, None
         dl, ldd = _alloc_rows(M, V, lg.device, zero_pad=True)
         call("ytvln_ce_bwd_f32", _ptr(lg), ld, _ptr(tg), ign, _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dl), ldd, M, V, _stream())
@@ -1365,7 +1379,8 @@ class KLMaskedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, mask):
         ctx.set_materialize_grads(False)
-        pr, M, Cc, ld = _rows2d(pred, "pred")
+        bf = pred.dtype == _BF16
+        pr, M, Cc, ld = _rows2d_any(pred) if bf else _rows2d(pred, "pred")
         tg, M2, C2, ldt = _rows2d(target, "target")
         assert (M, Cc) == (M2, C2), (pred.shape, target.shape)
         mk = _i64(mask, "mask").reshape(-1)
@@ -1373,9 +1388,10 @@ class KLMaskedFn(torch.autograd.Function):
         row_lse = torch.empty(M, dtype=torch.float32, device=dev)
         row_loss = torch.empty(M, dtype=torch.float32, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)
-        call("ytvln_kl_fwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(row_loss), _ptr(out), M, Cc, _stream())
+        call("ytvln_kl_fwd_bf16" if bf else "ytvln_kl_fwd_f32", pr.data_ptr(), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(row_loss),
+             _ptr(out), M, Cc, _stream())
         ctx.meta = (M, Cc, ld, ldt, pred.shape)
-        ctx.bf16_grad = _MATMUL_PRECISION == "bf16" and M * Cc >= (1 << 16)
+        ctx.bf16_grad = bf
         ctx.save_for_backward(pr, tg, mk, row_lse, out)
         return out[0]
 
@@ -1388,7 +1404,7 @@ class KLMaskedFn(torch.autograd.Function):
         g = g.reshape(1).contiguous().float()
         if ctx.bf16_grad:
             dp, ldd = _alloc_rows_bf16(M, Cc, pr.device)
-            call("ytvln_kl_bwd_bf16", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), dp.data_ptr(), ldd, M, Cc, _stream())
+            call("ytvln_kl_bwd_bf16", pr.data_ptr(), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), dp.data_ptr(), ldd, M, Cc, _stream())
             return _view_rows_as(dp, ldd, shape), None, None
         dp, ldd = _alloc_rows(M, Cc, pr.device, zero_pad=True)
         call("ytvln_kl_bwd_f32", _ptr(pr), ld, _ptr(tg), ldt, _ptr(mk), _ptr(row_lse), _ptr(out), _ptr(g), _ptr(dp), ldd, M, Cc, _stream())

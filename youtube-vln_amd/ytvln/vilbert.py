@@ -634,7 +634,7 @@ class BertLMPredictionHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
 
     def forward(self, hidden_states):
-        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.bias, out_fp32=True)       # logits feed the fp32 loss kernels
+        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.bias)       # bf16 logits on the bf16-resident path (the loss kernels read them)
 
 
 class BertOnlyMLMHead(nn.Module):
@@ -662,7 +662,7 @@ class BertImagePredictionHead(nn.Module):
         self.decoder = nn.Linear(config.v_hidden_size, config.v_target_size)
 
     def forward(self, hidden_states):
-        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.decoder.bias, out_fp32=True)
+        return ops.linear(self.transform(hidden_states), self.decoder.weight, self.decoder.bias)
 
 
 class BertPreTrainingHeads(nn.Module):
