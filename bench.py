@@ -83,6 +83,9 @@ def parse():
                          "target; same losses and gradients, fewer FLOPs than the reference's full decode")
     ap.add_argument("--kernel-table", action="store_true", help="print per-shape GEMM timing to stderr")
     ap.add_argument("--eval-dropout-off", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--host-probe", type=int, default=3, metavar="N",
+                    help="N extra steps after the timed region (0: none), each enqueued into EMPTY queues (device synchronised first): wall and "
+                         "CPU time of the enqueue alone = the host work of a step without back-pressure waits (tools/host8.py)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="(diagnostic, not a measurement configuration) run the N > 1 code path -- DataParallel wrapper, two-graph step, RCCL "
                          "all-reduce of the whole gradient arena through the C ABI communicator -- in a ONE-rank world on a single GPU")
@@ -519,8 +522,12 @@ def main():
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     c0 = time.thread_time()
+    pc0 = time.process_time()
+    enq = []
     for i in range(a.steps):
+        e0 = time.perf_counter()
         loss, _ = step(a.warmup + i)
+        enq.append(time.perf_counter() - e0)
     host_enqueue = time.perf_counter() - t0          # wall time until the last step is enqueued: INCLUDES waiting for room in the stream's queue
     host_cpu = time.thread_time() - c0               # CPU time this thread spent enqueueing: what N ranks on one host really compete for
     torch.cuda.synchronize()
@@ -528,8 +535,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_cpu_process = time.process_time() - pc0     # every thread of this rank until the steps have drained: + RCCL proxy / HIP runtime threads
     timer.on = ftimer.on = False
     elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)
+    host_probe = None
+    if a.host_probe > 0:
+        pw, pc, pd = [], [], []
+        for i in range(a.host_probe):
+            torch.cuda.synchronize()
+            w0, k0 = time.perf_counter(), time.thread_time()
+            loss, _ = step(a.warmup + a.steps + i)
+            w1 = time.perf_counter()
+            pc.append(1000.0 * (time.thread_time() - k0))
+            torch.cuda.synchronize()
+            pw.append(1000.0 * (w1 - w0))
+            pd.append(1000.0 * (time.perf_counter() - w1))
+        host_probe = {"steps": a.host_probe, "enqueue_wall_ms": {"p50": round(float(np.percentile(pw, 50)), 2), "max": round(max(pw), 2)},
+                      "enqueue_cpu_ms": {"p50": round(float(np.percentile(pc, 50)), 2), "max": round(max(pc), 2)},
+                      "drain_ms": {"p50": round(float(np.percentile(pd, 50)), 2), "max": round(max(pd), 2)},
+                      "note": "each step enqueued into empty queues: enqueue_* = until the step() call returns (host work of one step, no back-pressure "
+                              "waits); drain_ms = from there until the device has finished that step (the whole step was still ahead)"}
     final_loss = float(loss)
     assert np.isfinite(final_loss), "training diverged"
     # data parallel: after the timed steps every replica must hold the same parameters (each rank saw different data, so this holds only
@@ -634,9 +659,13 @@ def main():
         "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
         "host_enqueue_ms_per_step": round(1000.0 * control_reduce(host_enqueue, dist.ReduceOp.MAX) / a.steps, 2),
         "host_cpu_ms_per_step": round(1000.0 * control_reduce(host_cpu, dist.ReduceOp.MAX) / a.steps, 2),
+        "host_cpu_process_ms_per_step": round(1000.0 * host_cpu_process / a.steps, 2),          # this rank, all threads (incl. RCCL proxy / runtime)
+        "host_enqueue_ms_tail": {"p50": round(1000.0 * float(np.percentile(enq, 50)), 2), "max": round(1000.0 * max(enq), 2)},   # per step, this rank
         "host_cores_available": effective_cores(),
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
     }
+    if host_probe is not None:
+        out["host_probe"] = host_probe
     if replica_spread is not None:
         out["config"]["replica_checksum_spread"] = replica_spread
     if dp_diag is not None:

@@ -134,3 +134,35 @@ def test_gemm_launch_planner_host_logic():
     assert (tm, tn) == (256, 256) and sp >= 2
     assert plan_x3(4480, 3072, 768, epi=1)[2] == 1             # fused activations never split
     assert plan_x3(768, 768, 4480, transA=1)[:2] != (256, 256)   # 9 wide tiles cannot fill 256 CUs even with 16 k-slabs
+
+
+def test_integration_md_lists_every_knob():
+    """INTEGRATION.md section 4a is exhaustive: (1) its run-time options table = the library's own table (names AND defaults, read through
+    ytvln_option_name / ytvln_get_option in a clean environment); (2) its environment table = every YTVLN_* variable the host code reads
+    (grep of the Python sources for environ lookups), nothing more and nothing less; (3) the library reads no other YTVLN_* variable."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 4a."):text.index("## 5.")]
+    env_tab, opt_tab = sec.split("**Run-time options of the library**")
+    doc_env = set(re.findall(r"^\| `(YTVLN_\w+)` \|", env_tab, flags=re.M))
+    doc_opt = {m.group(1): int(m.group(2)) for m in re.finditer(r"^\| `([A-Z0-9_]+)` \| (-?\d+) \|", opt_tab, flags=re.M)}
+    # (1) the library's table, defaults read in a child process with no YTVLN_* variable set
+    code = ("import sys; sys.path.insert(0, %r); from ytvln import _lib; print(repr(_lib.options()))" % os.path.join(ROOT, "youtube-vln_amd"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YTVLN_")}
+    lib_opt = eval(subprocess.run([os.sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    assert doc_opt == lib_opt, (doc_opt, lib_opt)
+    # (2) environment reads of the host code (+ bench.py)
+    read = set()
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    pkg = os.path.join(ROOT, "youtube-vln_amd", "ytvln")
+    files += [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")]
+    for f in files:
+        src = open(f).read()
+        read |= set(re.findall(r"environ(?:\.get|\.setdefault)?\s*[\(\[]\s*\"(YTVLN_\w+)\"", src))
+        read |= set(re.findall(r"\"(YTVLN_\w+)\"\s+(?:not\s+)?in\s+os\.environ", src))
+    assert read == doc_env, (sorted(read - doc_env), sorted(doc_env - read))
+    # (3) the library builds its variable names from the option table only ("YTVLN_%s"): no literal getenv("YTVLN_...") anywhere in csrc
+    csrc = os.path.join(ROOT, "youtube-vln_amd", "csrc")
+    for f in os.listdir(csrc):
+        src = open(os.path.join(csrc, f)).read()
+        assert not re.findall(r"getenv\s*\(\s*\"YTVLN_", src), f
+        assert len(re.findall(r"getenv\s*\(", src)) == (1 if f == "misc.hip" else 0), f

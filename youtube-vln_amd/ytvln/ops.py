@@ -191,7 +191,7 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
     ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
     if _MATMUL_PRECISION == "fp32x3":
         flags = int(flags) | GEMM_SPLIT_BF16X3
-    if rowsum is not None and _FUSED_BIAS_GRAD:
+    if rowsum is not None:
         done = ctypes.c_int(0)
         call("ytvln_gemm_f32_rowsum", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
              M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _ptr(rowsum), ctypes.byref(done), _stream())
@@ -199,9 +199,6 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
     call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
          M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _stream())
     return False
-
-
-_FUSED_BIAS_GRAD = os.environ.get("YTVLN_FUSED_BIAS_GRAD", "1") != "0"      # experiment knob: 0 -> every bias gradient by ytvln_colsum_f32
 
 
 def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> Tensor:

@@ -20,9 +20,7 @@ from torch.optim.lr_scheduler import LambdaLR
 
 from . import ops
 
-import os as _os
 
-_DEBUG_ADOPT = [] if _os.environ.get("YTVLN_DEBUG_ADOPT") else None      # diagnostic: shapes of gradients that needed a copy into the arena
 CHUNK = 16384       # elements per workgroup of the fused kernel
 ALIGN = 4           # arena offsets are multiples of 4 floats (16-byte vector access)
 
@@ -199,8 +197,6 @@ class AdamW(Optimizer):
                     stale_data = True
                     break
                 if p.grad.data_ptr() != base_g + 4 * o:       # e.g. model.zero_grad() dropped the views: re-adopt
-                    if _DEBUG_ADOPT is not None:
-                        _DEBUG_ADOPT.append(tuple(p.shape))
                     fg[o:o + n].copy_(p.grad.reshape(-1))
                     p.grad = fg[o:o + n].view(p.shape)
         if stale_data:                                         # parameters were re-allocated (model.to(...)): rebuild
