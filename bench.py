@@ -686,12 +686,14 @@ def main():
         try:     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (cannot be collected in-process): the newest committed summary
             import glob
             import re
-            cands = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_summary.json"))
-                            if re.fullmatch(r"round\d+_pmc_summary\.json", os.path.basename(f))),
+            # fp32: roundN_pmc_summary.json (cfg 2); bf16: roundN_bf16_pmc_summary.json (collected at cfg 5: only quoted for that workload)
+            pat = r"round\d+_pmc_summary\.json" if a.precision == "fp32" else r"round\d+_bf16_pmc_summary\.json"
+            cands = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_summary.json")) if re.fullmatch(pat, os.path.basename(f))),
                            key=lambda f: int(re.search(r"round(\d+)_", os.path.basename(f)).group(1)))
             pmc = json.load(open(cands[-1]))
-            traffic = pmc["kernels"]["gemm_dma"]["hbm_side_bytes_per_launch"]
-            traffic_note = f"profiles/{os.path.basename(cands[-1])}: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
+            if a.precision == "fp32" or (a.precision == "bf16" and a.workload.startswith("cfg5")):
+                traffic = pmc["kernels"]["gemm_dma" if a.precision == "fp32" else "gemm_bf16"]["hbm_side_bytes_per_launch"]
+                traffic_note = f"profiles/{os.path.basename(cands[-1])}: (2 x FETCH_SIZE + WRITE_SIZE) per fast-path GEMM launch, separate --pmc passes"
         except (OSError, KeyError, ValueError, IndexError, AttributeError):
             pass
         # fp32x3: six bf16 matrix instructions per algorithmic product -> the ceiling for algorithmic FLOPs is the bf16 peak / 6
@@ -699,9 +701,8 @@ def main():
         kname = {"fp32": "ytvln::gemm_dma_kernel (v_mfma_f32_32x32x2_f32)",
                  "bf16": "ytvln::gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16; bf16 operands read in place, transposed operands by ds_read_b64_tr_b16)",
                  "fp32x3": "ytvln::gemm_dma_kernel<X3> (6 x v_mfma_f32_32x32x16_bf16 per product; peak = bf16 dense peak / 6)"}[a.precision]
-        if a.precision != "fp32":
-            traffic, traffic_note = None, None
         if a.precision == "fp32x3":
+            traffic, traffic_note = None, None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_n_fp32x3_pmc_summary.json")))
                 traffic = pmc["kernels"]["gemm_dma"]["hbm_side_bytes_per_launch"]
