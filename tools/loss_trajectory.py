@@ -1,6 +1,6 @@
 """Loss trajectories of the full model on ONE synthetic cfg-2 batch (dropout on, same mask stream) for the three projection arithmetics:
 native fp32 MFMA, fp32x3 and bf16.  Evidence that fp32x3 trains like fp32 and that the step is numerically healthy over
-hundreds of optimizer steps.  usage: python tools/loss_trajectory.py [steps] -> gpurun_out/round2_loss_trajectory.json"""
+hundreds of optimizer steps.  usage: python tools/loss_trajectory.py [steps] [tag] -> gpurun_out/<tag>_loss_trajectory.json (tag: round2)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "youtube-vln_amd")); sys.path.insert(0, ROOT)
@@ -12,6 +12,7 @@ from ytvln.vilbert import BertConfig
 from ytvln.vilbert_init import get_optimization
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+tag = sys.argv[2] if len(sys.argv) > 2 else "round2"
 cfgname, bs, K, T, frames, boxes, flags = bench.WORKLOADS["cfg2_full_pretrain_bs8"]
 dev = torch.device("cuda", 0)
 out = {"workload": "cfg2_full_pretrain_bs8 (56 pairs), one fixed synthetic batch, lr 4e-5 WarmupLinear, dropout on, seed 1234", "steps": steps, "loss": {}}
@@ -37,6 +38,8 @@ for prec in ("fp32", "fp32x3", "bf16"):
 ops.set_matmul_precision("fp32")
 a, b = dict(out["loss"]["fp32"]), dict(out["loss"]["fp32x3"])
 out["max_abs_diff_fp32x3_vs_fp32"] = max(abs(a[k] - b[k]) for k in a)
+c = dict(out["loss"]["bf16"])
+out["max_rel_diff_bf16_vs_fp32"] = max(abs(a[k] - c[k]) / max(abs(a[k]), 1e-6) for k in a)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "round2_loss_trajectory.json"), "w"), indent=1)
-print("max |fp32x3 - fp32| over the trajectory:", out["max_abs_diff_fp32x3_vs_fp32"])
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_loss_trajectory.json"), "w"), indent=1)
+print("max |fp32x3 - fp32| over the trajectory:", out["max_abs_diff_fp32x3_vs_fp32"], " max rel |bf16 - fp32|:", out["max_rel_diff_bf16_vs_fp32"])

@@ -1,7 +1,7 @@
 """Soak run of the captured training step: the full cfg-2 model, hipGraph replay, a DIFFERENT synthetic batch copied into the static input
 tensors before every replay (8 batches in rotation), AdamW + WarmupLinear, dropout on.  Checks every 25 steps that the loss is finite,
 that device memory does not grow, and reports the loss curve (random labels: the loss settles at the chance level of the four heads).
-usage: python tools/soak.py [steps] -> gpurun_out/round2_soak.json"""
+usage: python tools/soak.py [steps] [tag] [precision] -> gpurun_out/<tag>_soak.json (tag: round2, precision: fp32)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "youtube-vln_amd")); sys.path.insert(0, ROOT)
@@ -13,10 +13,13 @@ from ytvln.vilbert import BertConfig
 from ytvln.vilbert_init import get_optimization
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+tag = sys.argv[2] if len(sys.argv) > 2 else "round2"
+precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 cfgname, bs, K, T, frames, boxes, flags = bench.WORKLOADS["cfg2_full_pretrain_bs8"]
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
 ops.DropoutState.manual_seed(1234)
+ops.set_matmul_precision(precision)
 args = bench.make_args(flags)
 cfg = BertConfig.from_json_file(os.path.join(ROOT, "youtube-vln_amd", "configs", cfgname)); cfg.args = args
 model = Lily(cfg).to(dev).train()
@@ -52,5 +55,5 @@ out = {"workload": "cfg2_full_pretrain_bs8 (56 pairs/step), hipGraph replay, 8 s
        "memory_reserved_gb": {"first": mem[0], "last": mem[-1], "max": max(mem)}, "non_finite_parameters": bad}
 assert not bad and mem[-1] == mem[0], out
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "round2_soak.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_soak.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "loss"}), curve[0], curve[len(curve) // 2], curve[-1])
