@@ -12,7 +12,7 @@ Prints ONE JSON line (rank 0).  Besides the driver contract it carries
   roofline     -- the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their HIP-event time, measured
                   live on the launch stream during the timed steps, against the 157.3 TFLOP/s fp32 matrix peak;
   variants     -- (N = 1, default precision only; NOT the headline) the same captured step re-timed with the opt-in fp32x3 projections
-                  (fp32 operands, three exact bf16 terms per value, six bf16 MFMAs per product) and with bf16 operands
+                  (fp32 operands, three exact bf16 terms per value, six bf16 MFMAs per product; LABNOTES.md 5a) and with bf16 operands
                   (the arithmetic of BASELINE configs[4]); --no-variants skips them;
   cpu_baseline -- the CPU oracle (a port of the reference's path, oracle/vilbert_ref.py) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only).
@@ -747,7 +747,7 @@ def main():
                 print(f"{M:7d} {N:6d} {Kk:6d} {ta:2d} {tb:2d} {c:6d} {msx:9.3f} {fl / msx / 1e9:7.1f}", file=sys.stderr)
     if world == 1 and not dp_wrap and a.precision == "fp32" and use_graph and a.h2d == "off" and not a.no_variants:
         # NOT the headline: the same captured step with the opt-in fp32x3 projections (fp32 operands, three exact bf16 terms per value,
-        # six bf16 MFMAs per product; same parity bar as the native instruction), timed after everything above.
+        # six bf16 MFMAs per product; same parity bar as the native instruction, LABNOTES.md 5a), timed after everything above.
         def time_variant(mode, base):
             """pairs/s and ms/step of the same step captured again under another projection arithmetic (after the headline is timed)"""
             yt_ops.set_matmul_precision(mode)
@@ -796,7 +796,7 @@ def main():
                                                  "instantiation; the <..., false, true> launches belong to variants.fp32x3 (--no-variants omits them)")
             out["variants"] = {"fp32x3": {"value": v3, "unit": "pairs/s", "ms_per_step": ms3,
                                           "note": "opt-in --precision fp32x3, not the headline: fp32 operands split exactly into 3 bf16 terms in "
-                                                  "registers, 6 bf16 MFMAs per product, f32 accumulate; meets the fp32 parity bar (DESIGN.md 5a)",
+                                                  "registers, 6 bf16 MFMAs per product, f32 accumulate; meets the fp32 parity bar (LABNOTES.md 5a)",
                                           "gemm_4096x1024x1024_max_err_over_max_vs_f64": {"native_f32_mfma": float(f"{errs['fp32']:.3e}"),
                                                                                           "fp32x3": float(f"{errs['fp32x3']:.3e}")}}}
         except Exception as e:      # never let the extra measurement endanger the headline line

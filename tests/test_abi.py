@@ -122,7 +122,7 @@ def test_gemm_launch_planner_host_logic():
     assert (tm, tn) == (256, 256) and sp <= 2
     assert lib.ytvln_gemm_plan(0, 8, 8, 0, 0, None, None, None) != 0
 
-    def plan_x3(M, N, K, transA=0, epi=0):      # the three-bf16-term form of the fp32 GEMM has its own cost table
+    def plan_x3(M, N, K, transA=0, epi=0):      # the three-bf16-term form of the fp32 GEMM has its own cost table (LABNOTES.md 5a)
         tm, tn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         assert lib.ytvln_gemm_plan_x3(M, N, K, transA, epi, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp)) == 0
         return tm.value, tn.value, sp.value

@@ -1,5 +1,5 @@
 """Loss trajectories of the full model on ONE synthetic cfg-2 batch (dropout on, same mask stream) for the three projection arithmetics:
-native fp32 MFMA, fp32x3 and bf16.  Evidence that fp32x3 trains like fp32 and that the step is numerically healthy over
+native fp32 MFMA, fp32x3 and bf16.  Evidence that fp32x3 trains like fp32 (LABNOTES.md 5a) and that the step is numerically healthy over
 hundreds of optimizer steps.  usage: python tools/loss_trajectory.py [steps] [tag] -> gpurun_out/<tag>_loss_trajectory.json (tag: round2)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -666,7 +666,7 @@ struct W1Stream {
 // tile and relies on the d-split trick for its half-empty workgroups.  Image self-attention (56 pairs) 262 -> 224 us, co-attention pair
 // 181 -> 163 us.  Round 3 also built and measured a software-pipelined one-wave form (softmax of tile t written between the matrix instructions
 // of S(t+1), DMA pieces spread over the P.V steps; ISA checked): 246 us -- a wave's VALU time is NOT hidden under its own matrix instructions,
-// the times add (profiles/round3_attn_w1_probes.log), so the interleaving only added control overhead and was removed.
+// the times add (LABNOTES.md 5c; profiles/round3_attn_w1_probes.log), so the interleaving only added control overhead and was removed.
 // Same arithmetic, same order as attn_fwd_body: the forms agree to rounding (tests/test_attention_forms_gpu.py).
 template <int DP, bool DROP>
 __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx, const int h, const int n) {

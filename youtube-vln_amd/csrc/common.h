@@ -98,7 +98,7 @@ __device__ __forceinline__ float drop_scale1(const DropKey& k, uint64_t e, uint3
 // once per wave, so that neighbouring sites and steps get unrelated keys -- by xor; then five FULL-RATE operations: a 24-bit multiply-add
 // (v_mad_u32_u24, fed by the low 24 bits, the high 24 added back), an xor-shift, a 24-bit multiply.  Round 3: replaces the murmur3 finaliser
 // applied per element (2 quarter-rate v_mul_lo_u32 + 6 plain ops = 56 issue cycles of the ~100 a score element cost each attention kernel;
-// now 20) -- a wave's VALU time is not hidden under its matrix instructions.  Quality, measured against the finaliser on
+// now 20) -- a wave's VALU time is not hidden under its matrix instructions (LABNOTES.md 5c).  Quality, measured against the finaliser on
 // 4096 x 288 masks at p = 0.1 over 60 random key pairs: drop rate 0.1000 (0.0992-0.1006 per mask), correlations between neighbours along keys /
 // rows / diagonals / +32 keys <= 0.003, correlation between the masks of two keys 0.0009 rms / 0.0033 max -- all at the sampling-noise floor
 // (0.0009), as for the finaliser.  (A version with ONE 32-bit multiply also passes the single-mask tests but leaves 0.0025 rms / 0.013 max

@@ -10,8 +10,8 @@
 // (row pitch BM+1 -> conflict-free); operands with M/N contiguous (dY^T, x^T views for the backward GEMMs) are written
 // with 16-byte stores (row pitch BM).
 // (That paragraph describes gemm_f32_kernel, the generic register-staged kernel.  The production path is gemm_dma_kernel further
-//  down: LDS-DMA operand delivery, 64x64 ... 256x256 tiles, fused epilogues, deterministic split-K; the same kernel also exists with
-//  bf16-staged operands (BF16) and in the three-bf16-term form of fp32 (X3, YTVLN_GEMM_SPLIT_BF16X3).)
+//  down: LDS-DMA operand delivery, 64x64 ... 256x256 tiles, fused epilogues, deterministic split-K; the same kernel also exists in
+//  the three-bf16-term form of fp32 (X3, YTVLN_GEMM_SPLIT_BF16X3); bf16 operands have their own kernels in gemm_bf16.hip.)
 #include "common.h"
 #include <algorithm>
 #include <vector>
@@ -358,10 +358,6 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // KB: k-tile depth (32 or 16), NS: LDS ring depth (NS - 1 k-tiles of DMA in flight under the MFMAs), WPS: waves per SIMD the
 // register budget is sized for (= resident workgroups per CU x NW / 4).
 //
-// BF16 = true: the operands are bf16 matrices (both K-contiguous) seen as float arrays of half the width -- the byte geometry
-// of tiles, DMA pieces and swizzle is unchanged; a 16-byte granule now holds the 8 consecutive k one lane feeds to
-// v_mfma_f32_32x32x16_bf16, so every k-group is ONE matrix instruction per accumulator instead of four (granule 4*half + sg:
-// the k-slots of the two half-waves are any fixed, identical split for A and B).  Accumulation and epilogue stay fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // X3 = true ("fp32 by three bf16 terms"): the operands stay fp32 in HBM and LDS; a lane splits the eight consecutive k it owns
@@ -395,10 +391,8 @@ __device__ __forceinline__ Split3 split3(const float4 u, const float4 v) {
     return s;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool BF16 = false, bool X3 = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g) {
-    static_assert(!BF16 || (A_KC && B_KC && KB == 32), "bf16 operands are staged K-contiguous");
-    static_assert(!(BF16 && X3), "the split applies to fp32 operands");
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
     constexpr int WM = NW / 2;                         // waves along m (x 2 along n)
@@ -436,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
 
     // Row sums of op(A) over this workgroup's k range (db = sum over rows of dY, riding on dW = dY^T X): every tile column reads the same
     // A panel, so the workgroups of tile column 0 (and there the waves of wave column 0) add up the fragments they feed to the MFMAs.
-    const bool do_asum = !A_KC && !BF16 && !X3 && g.asum != nullptr && tc.n == 0 && (wave & 1) == 0;
+    const bool do_asum = !A_KC && !X3 && g.asum != nullptr && tc.n == 0 && (wave & 1) == 0;
     float asum[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
@@ -526,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             float4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
-            if constexpr (!A_KC && !BF16) {
+            if constexpr (!A_KC) {
                 if (do_asum) {             // wave-uniform: first tile column, first wave column
 #pragma unroll
                     for (int i = 0; i < TM; ++i) asum[i] += (a[i].x + a[i].y) + (a[i].z + a[i].w);
@@ -538,20 +532,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (BF16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
-                                                                             acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
         }
     }
-    if constexpr (!A_KC && !BF16 && !X3) {
+    if constexpr (!A_KC && !X3) {
         if (do_asum) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -575,10 +564,10 @@ void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsign
 template <int BM, int BN, int NW, int WPS>
 static void launch_x3_tile(const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
     const dim3 gr(grid), blk(NW * 64);
-    if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
-    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, 32, 2, WPS, false, true>), gr, blk, 0, s, g);
+    if (!transA && transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, true, NW, 32, 2, WPS, true>), gr, blk, 0, s, g);
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, true, false, NW, 32, 2, WPS, true>), gr, blk, 0, s, g);
+    else if (transA && !transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, false, NW, 32, 2, WPS, true>), gr, blk, 0, s, g);
+    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, false, true, NW, 32, 2, WPS, true>), gr, blk, 0, s, g);
 }
 void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s) {
     if (bm == 256 && bn == 256) launch_x3_tile<256, 256, 8, 2>(g, transA, transB, grid, s);     // 8 waves of 64x128, one workgroup per CU
