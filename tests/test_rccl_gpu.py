@@ -30,12 +30,17 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _build(dev):
+# the bf16-resident attention kernels exist for head dimensions 64 / 128: the micro config widened to two heads of 64 in every stream
+_WIDE = dict(hidden_size=128, num_attention_heads=2, intermediate_size=128, v_hidden_size=128, v_num_attention_heads=2, v_intermediate_size=128,
+             bi_hidden_size=128, bi_num_attention_heads=2)
+
+
+def _build(dev, wide=False):
     from ytvln import synth
     from ytvln.lily import Lily
     from ytvln.vilbert import BertConfig
     args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
-    cfg = BertConfig(**cfg_dict("micro.json", **ZERO_DROP))
+    cfg = BertConfig(**cfg_dict("micro.json", **ZERO_DROP, **(_WIDE if wide else {})))
     cfg.args = args
     model = Lily(cfg, dropout_prob=0.0)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -52,10 +57,18 @@ def _flat(model):
     return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
 
 
-def _plain_run(dev, steps=3):
-    from ytvln import utils_init as U
+def _plain_run(dev, steps=3, precision="fp32", wide=False):
+    from ytvln import ops, utils_init as U
     from ytvln.vilbert_init import get_optimization
-    model, args = _build(dev)
+    ops.set_matmul_precision(precision)
+    try:
+        return _plain_run_body(dev, steps, U, get_optimization, precision != "fp32" or wide)
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
+def _plain_run_body(dev, steps, U, get_optimization, wide):
+    model, args = _build(dev, wide)
     args.learning_rate = 1e-3
     opt, sched, _, _ = get_optimization(args, model, 10, None)
     batch = _batch(dev)
@@ -75,6 +88,9 @@ def _worker(case, port, q):
         from ytvln.vilbert_init import get_optimization
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
+        case, _, precision = case.partition("@")          # "...@bf16": the bf16-resident path (bf16 weight arena written by AdamW, bf16 activations)
+        from ytvln import ops
+        ops.set_matmul_precision(precision or "fp32")
         collective, mode = case.split(":")
         metrics = mode.endswith("+metrics")       # the reference's default: local_rank != -1 and --skip_all_reduce off -> logged metrics are all-reduced
         mode = mode.replace("+metrics", "")
@@ -83,7 +99,7 @@ def _worker(case, port, q):
             mode = "phased"
         D.init_distributed(backend="nccl" if collective == "torch" else "gloo", force=True)
         assert dist.get_world_size() == 1 and dist.get_backend() == ("nccl" if collective == "torch" else "gloo")
-        model, args = _build(dev)
+        model, args = _build(dev, wide=bool(precision))
         args.learning_rate = 1e-3
         if metrics:
             args.local_rank, args.skip_all_reduce = 0, False
@@ -137,7 +153,7 @@ def _worker(case, port, q):
 
 
 @pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "rccl:phased", "rccl:phased3", "torch:eager", "torch:split",
-                                  "rccl:eager+metrics", "rccl:split+metrics", "rccl:phased+metrics"])
+                                  "rccl:eager+metrics", "rccl:split+metrics", "rccl:phased+metrics", "rccl:eager@bf16", "rccl:phased@bf16"])
 def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -147,8 +163,11 @@ def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     p.join(timeout=120)
     assert status == "ok", got
     assert p.exitcode == 0
-    ref = _plain_run(dev)
+    case, _, precision = case.partition("@")
+    ref = _plain_run(dev, precision=precision or "fp32")
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())     # identity exchange, grad_scale 1: bit-identical
+    if precision:
+        assert not np.array_equal(ref, _plain_run(dev, wide=True)), "the bf16-resident run must differ from the fp32 one"
     if case.startswith("rccl"):
         assert "rccl" in os.path.basename(info["library"])
     if case == "rccl:phased3":

@@ -1091,6 +1091,10 @@ def image_embed(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps=1e-12, p=0
     if _CHECK_INDICES:
         _check_index_range(loc[..., 11].long(), E.shape[0], "frame index (image_loc[..., 11])")
     use = drop is not None and p > 0
+    if _MATMUL_PRECISION == "bf16" and img.dtype == torch.float32:
+        # both streams of the bf16-resident path are bf16 (co-attention reads them side by side); a feature projection too small for the bf16
+        # GEMM (K < 64: toy configs) leaves its output fp32 -- round it here, autograd casts the gradient back
+        img = img.to(torch.bfloat16)
     return ImageEmbedFn.apply(img, loc, W5, b5, W4, b4, W2, b2, E, gamma, beta, eps, p if use else 0.0,
                               drop.tensor if use else None, drop.next_site() if use else 0)
 
