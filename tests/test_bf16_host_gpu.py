@@ -152,3 +152,44 @@ def test_loss_subsets_and_eval_mode_against_fp32(dev, lib, flags):
     for n, p in model.named_parameters():
         if p.grad is not None:
             assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), n
+
+
+def test_g12_cfg4_finetune_full_size_bf16(dev, lib):
+    """BASELINE configs[3] shapes on the bf16-resident path: fine-tune --ranking, 96 rows, R = 7 x 36 = 252 regions -- NOT a multiple of the
+    32-row attention tiles (clamped tail rows in every bf16 attention kernel) -- against the reference golden with the bf16 bars."""
+    from ytvln import synth
+    from test_model_gpu import FULL_CFG, _bf16_check, gold
+    g = gold("g12_cfg4_full_n96.npz")
+    args = args_ns(ranking=True, pretrain=False, num_negatives=2)
+    model, _ = build_lily(dev, FULL_CFG, args, seed=33)
+    batch = synth.to_torch(synth.make_batch(bs=16, K=6, T=80, frames=7, boxes=36, seed=43, finetune_heading=True), dev)
+    _bf16_check(model, batch, args, g)
+
+
+def test_inference_rerank_shapes_bf16_against_fp32(dev, lib):
+    """The re-ranking inference shapes (30 beams, R = 8 x 101 = 808 regions, T = 60, a ragged opt_mask, eval mode) through eval_epoch: the bf16
+    scores stay within 2e-2 of the fp32 scores' spread and both pick the same best beam wherever the fp32 margin exceeds that."""
+    from ytvln import ops, synth, utils_init as U
+    args = args_ns(ranking=True, pretrain=False)
+    model, _ = build_lily(dev, CFG, args, seed=31)
+    model.eval()
+    nb = synth.make_batch(bs=2, K=30, T=60, frames=8, boxes=101, seed=77, finetune_heading=True, ignore_rank_frac=0.0)
+    nb[13][1, 25:] = False
+    nb[12] = np.array([[4051, 0], [4051, 2]], np.int64)
+    batch_cpu = synth.to_torch(nb)
+    s32 = U.eval_epoch(model, [batch_cpu], args)
+    ops.set_matmul_precision("bf16")
+    try:
+        s16 = U.eval_epoch(model, [batch_cpu], args)
+    finally:
+        ops.set_matmul_precision("fp32")
+    assert [s[0] for s in s16] == [s[0] for s in s32]
+    a, b = torch.tensor([s[1] for s in s32]), torch.tensor([s[1] for s in s16])
+    valid = batch_cpu[13]
+    spread = float(a[valid].max() - a[valid].min())
+    assert float((a - b)[valid].abs().max()) < 2e-2 * max(spread, 1.0), (float((a - b)[valid].abs().max()), spread)
+    assert not torch.equal(a[valid], b[valid]), "bf16 mode reproduced the fp32 scores exactly: the bf16 path did not run"
+    for ra, rb, v in zip(a, b, valid):
+        top2 = torch.topk(ra[v], 2).values
+        if float(top2[0] - top2[1]) > 4e-2 * max(spread, 1.0):
+            assert int(torch.argmax(ra[v])) == int(torch.argmax(rb[v]))
