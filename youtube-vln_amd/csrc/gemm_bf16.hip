@@ -146,9 +146,6 @@ struct BfFrag {
     }
 };
 
-template <int N>
-__device__ __forceinline__ void bf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
 // lane owns column l31 of each 32x32 tile, rows (r & 3) + 8 (r >> 2) + 4 h.  Epilogue kind and the "tile inside the matrix" test are resolved
 // once per wave (uniform branches around specialised loops), as in gemm.hip.
