@@ -1,7 +1,7 @@
 """Soak run of the captured training step: the full cfg-2 model, hipGraph replay, a DIFFERENT synthetic batch copied into the static input
 tensors before every replay (8 batches in rotation), AdamW + WarmupLinear, dropout on.  Checks every 25 steps that the loss is finite,
 that device memory does not grow, and reports the loss curve (random labels: the loss settles at the chance level of the four heads).
-usage: python tools/soak.py [steps] [tag] [precision] -> gpurun_out/<tag>_soak.json (tag: round2, precision: fp32)"""
+usage: python tools/soak.py [steps] [tag] [precision] [workload] -> gpurun_out/<tag>_soak.json (tag: round2, precision: fp32, workload: cfg2_full_pretrain_bs8)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "youtube-vln_amd")); sys.path.insert(0, ROOT)
@@ -15,7 +15,8 @@ from ytvln.vilbert_init import get_optimization
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 tag = sys.argv[2] if len(sys.argv) > 2 else "round2"
 precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
-cfgname, bs, K, T, frames, boxes, flags = bench.WORKLOADS["cfg2_full_pretrain_bs8"]
+workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2_full_pretrain_bs8"
+cfgname, bs, K, T, frames, boxes, flags = bench.WORKLOADS[workload]
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
 ops.DropoutState.manual_seed(1234)
@@ -50,7 +51,7 @@ for i in range(steps):
 torch.cuda.synchronize()
 el = time.time() - t0
 bad = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
-out = {"workload": "cfg2_full_pretrain_bs8 (56 pairs/step), hipGraph replay, 8 synthetic batches in rotation copied into the static inputs, dropout on",
+out = {"workload": f"{workload} ({bs * K} pairs/step), precision {precision}, hipGraph replay, 8 synthetic batches in rotation copied into the static inputs, dropout on",
        "steps": steps, "seconds": round(el, 1), "pairs_per_s_including_refill": round(steps * bs * K / el, 1), "loss": curve,
        "memory_reserved_gb": {"first": mem[0], "last": mem[-1], "max": max(mem)}, "non_finite_parameters": bad}
 assert not bad and mem[-1] == mem[0], out
