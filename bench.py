@@ -74,6 +74,9 @@ def parse():
                     help="fp32 (default, the headline: the reference's arithmetic on the fp32 matrix instruction); bf16: dense projections "
                          "on bf16 MFMA operands with fp32 accumulation, everything else fp32 (BASELINE configs[4]); fp32x3: fp32 operands, "
                          "each value split exactly into three bf16 terms in registers, six bf16 MFMAs per product (fp32-level error)")
+    ap.add_argument("--two-stream", choices=["on", "off"], default="on",
+                    help="on: the text side of the model is enqueued on a second HIP stream (ytvln.ops.set_two_stream; results are bit-identical, "
+                         "the two sides become two branches of the captured graph and fill each other's idle CUs)")
     ap.add_argument("--h2d", choices=["off", "serial", "overlap", "compact"], default="off",
                     help="also move the batch from pinned host memory to HBM every step (NOT the headline: `value` is quoted with inputs "
                          "resident in HBM): serial = on the compute stream before the step, overlap = on a copy stream under the previous step, "
@@ -353,6 +356,7 @@ def main():
     from ytvln import synth, utils_init
     from ytvln.distributed import DataParallel
     yt_ops.set_matmul_precision(a.precision)
+    yt_ops.set_two_stream(a.two_stream == "on")
     from ytvln.lily import Lily
     from ytvln.vilbert import BertConfig
     from ytvln.vilbert_init import get_optimization
@@ -632,6 +636,7 @@ def main():
     roofline_note = "HIP events around every GEMM launch during the timed steps"
     if use_graph and not a.no_kernel_timing:
         n_prof = min(a.steps, 3)
+        yt_ops.set_two_stream(False)          # single kernels are timed alone on the chip (one stream), whatever the timed replays used
         eager_step(a.warmup + a.steps)        # untimed: eager launches allocate outside the graph's memory pool the first time
         torch.cuda.synchronize()
         timer.on = ftimer.on = True
@@ -639,6 +644,7 @@ def main():
             eager_step(a.warmup + a.steps + 1 + i)
         torch.cuda.synchronize()
         timer.on = ftimer.on = False
+        yt_ops.set_two_stream(a.two_stream == "on")
         roofline_note = f"HIP events around every GEMM launch during {n_prof} eager steps run right after the timed graph replays"
 
     pairs_per_step = bs * K * world
@@ -655,7 +661,7 @@ def main():
                    "pairs_per_gpu": bs * K, "global_pairs": pairs_per_step, "tokens": T, "regions": frames * boxes, "feature_dim": 2048,
                    "losses": [k for k, v in flags.items() if v], "dropout": not a.eval_dropout_off,
                    "optimizer": "fused AdamW (HF formula) + WarmupLinear", "parallelism": f"dp{world}",
-                   "execution": execution, "heads": "loss-aware rows (extension)" if a.loss_aware_heads else "all rows (reference)"},
+                   "execution": execution + (", text side on a second HIP stream (two graph branches)" if a.two_stream == "on" else ""), "heads": "loss-aware rows (extension)" if a.loss_aware_heads else "all rows (reference)"},
         "items_per_s": round(value / K, 3), "final_loss": round(final_loss, 4),
         "host_enqueue_ms_per_step": round(1000.0 * control_reduce(host_enqueue, dist.ReduceOp.MAX) / a.steps, 2),
         "host_cpu_ms_per_step": round(1000.0 * control_reduce(host_cpu, dist.ReduceOp.MAX) / a.steps, 2),

@@ -403,6 +403,61 @@ def test_graph_replay_equals_eager(dev, lib):
     assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_stream_equals_one_stream(dev, lib, precision):
+    """ops.set_two_stream(True) sends the text side of the model (vilbert.py:737-811: independent of the image side between co-attention
+    layers) to a second HIP stream.  Same kernels, same call order, same dropout sites: parameters after five steps (dropout on) must be
+    BIT-identical to the one-stream run, with eager launches and as two branches of a replayed hipGraph."""
+    from ytvln import ops, synth
+    from ytvln import utils_init as U
+    from ytvln.vilbert_init import get_optimization
+    args = args_ns(ranking=True, traj_judge=True, masked_vision=True, masked_language=True)
+    args.learning_rate = 1e-3
+    if precision == "fp32":
+        cfg = "micro.json"
+        batch = synth.to_torch(synth.make_batch(bs=2, K=3, T=8, frames=2, boxes=3, F=16, C=11, vocab=97, seed=21, ignore_rank_frac=0.0), dev)
+    else:
+        cfg = "tiny_2_2_1.json"      # head dimension 64: the bf16-resident attention kernels
+        batch = synth.to_torch(synth.make_batch(bs=2, K=7, T=16, frames=2, boxes=4, seed=22, ignore_rank_frac=0.0), dev)
+    finals, losses = {}, {}
+    ops.set_matmul_precision(precision)
+    try:
+        for two in (False, True):
+            for mode in ("eager", "graph"):
+                ops.set_two_stream(two)
+                ops.DropoutState.manual_seed(1234)
+                model, _ = build_lily(dev, cfg, args, seed=11)
+                model.train()
+                opt, sched, _, _ = get_optimization(args, model, 10, None)
+                for i in range(2):
+                    U.train_step(model, opt, sched, batch, args, i, all_options=True)
+                if mode == "eager":
+                    for i in range(2, 5):
+                        loss, _ = U.train_step(model, opt, sched, batch, args, i, all_options=True)
+                else:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        loss, _ = U.train_step(model, opt, None, batch, args, 0, all_options=True)
+                    for i in range(2, 5):
+                        opt.prepare_replay()
+                        g.replay()
+                        sched.step()
+                torch.cuda.synchronize()
+                assert not ops.TwoStream.active
+                finals[two, mode] = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+                losses[two, mode] = float(loss)
+    finally:
+        ops.set_two_stream(True)          # the default
+        ops.set_matmul_precision("fp32")
+        ops.DropoutState.manual_seed(None)
+    ref = finals[False, "eager"]
+    assert torch.isfinite(ref).all()
+    for key, val in finals.items():
+        assert losses[key] == losses[False, "eager"], (key, losses)
+        assert torch.equal(val, ref), (key, float((val - ref).abs().max()))
+
+
 def test_save_resume_and_eval_loops(dev, lib, tmp_path):
     """save_model -> get_optimization(--resume) continues bit-for-bit like an uninterrupted run; val_epoch / test_epoch agree
     with a direct evaluation (reference utils_init.py:277-295, 315-446, vilbert_init.py:44-70)."""
@@ -842,7 +897,8 @@ PRETRAIN = dict(ranking=True, traj_judge=True, masked_vision=True, masked_langua
 
 
 def _bf16_check(model, batch, args, g):
-    """bf16 MFMA mode against an fp32 golden: losses within 2e-2 relative, gradient norms within 5 % (+1e-4), never bit-equal."""
+    """bf16 MFMA mode against an fp32 golden: losses within 2e-2 relative, gradient norms within 5 % (+1e-4; 10 % for the co-attention
+    query / key projections), never bit-equal."""
     from ytvln import ops
     model.train()
     ops.set_matmul_precision("bf16")
@@ -861,9 +917,14 @@ def _bf16_check(model, batch, args, g):
     assert worst > 1e-7, "bf16 mode reproduced the fp32 losses exactly: the bf16 path did not run"
     pd = dict(model.named_parameters())
     assert {n for n, p in model.named_parameters() if p.grad is None} == set(g["unused"].tolist())
+    # 5 % per tensor; 10 % for the query / key projections of BertBiAttention: their gradient goes through dS = P o (dP - delta), a difference
+    # of two nearly equal bf16-rounded sums when a direction attends almost uniformly over 252-576 regions (measured: one co-layer of cfg 4 at
+    # -9 %, deterministic -- the runs that used to land inside 5 % did so through a since-fixed race in the bf16 forward kernel)
+    def bar(n):
+        return 1e-1 if ("biattention.query" in n or "biattention.key" in n) else 5e-2
     bad = [(n, float(pd[n].grad.double().norm()), float(ref)) for n, ref in zip(g["grad_names"].tolist(), g["grad_norms"])
-           if abs(float(pd[n].grad.double().norm()) - ref) > 5e-2 * ref + 1e-4]
-    assert not bad, bad[:5]
+           if abs(float(pd[n].grad.double().norm()) - ref) > bar(n) * ref + 1e-4]
+    assert not bad, bad
 
 
 def test_g10_cfg5_long_trajectories_full_model_fp32_and_bf16(dev, lib):

@@ -107,6 +107,10 @@ __device__ __forceinline__ LaneOff make_lane_off(int l31, int half) {
 // LDS reads in the tile loops go through __restrict__ parameters: a ds_read without alias information makes hipcc emit
 // s_waitcnt vmcnt(0) in front of it whenever an LDS-DMA is in flight (it might alias the DMA's destination), which drains the
 // prefetch of the next tile in the middle of the current one.
+// Before a tile buffer is handed back to the LDS-DMA every LDS read of it must have RETURNED: the reads feed matrix instructions, which hipcc
+// may sink -- together with the s_waitcnt lgkmcnt in front of them -- below the next global_load_lds (seen in the ISA of the bf16 kernels,
+// attention_bf16.hip: b_reads_done, where a DMA that hits in L1 / L2 overtook queued reads).  A compiler barrier does not order that; a wait does.
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float4 lds4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float2 lds2(const float* __restrict__ p) { return *reinterpret_cast<const float2*>(p); }
 
@@ -729,7 +733,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else w1_wait<DP / 8>();
         const f32x16 S = mma_rows<DP, W1_PIPE>(Ks, Qr, lo);
-        asm volatile("" ::: "memory");
+        lds_reads_done();
         if (more) ks.issue(j0 + 32);
         if constexpr (FIRST) {
 #pragma unroll
@@ -775,7 +779,7 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mma_regs_rows<DP, W1_PIPE>(O, P, Vs, lo);
-        asm volatile("" ::: "memory");
+        lds_reads_done();
         if (more) vs.issue(j0 + 32);
     };
     if (ntiles == 1) {
@@ -884,7 +888,7 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
         if (FIRST) w1_wait<2 * (DP / 8)>();
         else w1_wait<DP / 8>();
         const f32x16 dP = mma_rows<DP, W1_PIPE>(Vs, Gr, lo);
-        asm volatile("" ::: "memory");
+        lds_reads_done();
         if (more) vtile(j0 + 32);
         // K(t) (and, in the first tile, Q).  Behind them: V(t+1) if there is one, and in the first tile the O fragment
         if (FIRST) { if (more) w1_wait<2 * (DP / 8)>(); else w1_wait<DP / 8>(); }
@@ -919,7 +923,7 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
             }
         }
         mma_regs_rows<DP, W1_PIPE>(dQ, dS, Ks, lo);
-        asm volatile("" ::: "memory");
+        lds_reads_done();
         if (more) ktile(j0 + 32);
     };
     tile(std::true_type{}, 0);
@@ -1134,10 +1138,10 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
             }
         }
         mma_regs_rows<DP, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
-        asm volatile("" ::: "memory");
+        lds_reads_done();
         if (more) qtile(i0 + 32);
         mma_regs_rows<DP, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
-        asm volatile("" ::: "memory");
+        lds_reads_done();
         if (more) gtile(i0 + 32);
     };
     for (int t = 0; t + 1 < nqt; ++t) tile(std::true_type{}, t);

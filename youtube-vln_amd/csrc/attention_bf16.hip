@@ -47,6 +47,13 @@ struct BAttnLaunch { BAttnArgs p[2]; int nb0, gx0, gx1; };
 
 __device__ __forceinline__ int bkrow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 __device__ __forceinline__ float bscore(float s, float scale, float mask) { return __fadd_rn(__fmul_rn(s, scale), mask); }
+// Before a tile buffer is handed back to the LDS-DMA: every LDS read of it must have RETURNED, not merely been issued.  The reads feed matrix
+// instructions, and hipcc is free to sink those (and the s_waitcnt lgkmcnt in front of them) below the next global_load_lds: the DMA of a
+// tile that hits in L1 / L2 (the other query blocks of the same head load the same keys) then overtakes reads still queued behind the other
+// waves of the CU and a whole 32-row block of the output is computed from a half-replaced tile (seen as 1-3 wrong blocks in ~3500 per launch,
+// tools/bf16_repro.py).  A compiler barrier is not enough; this is.
+__device__ __forceinline__ void b_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void b_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -227,7 +234,7 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) S = MFMA_B(T::kc(Ks, l31, half, s), Qr[s], S);
-        asm volatile("" ::: "memory");
+        b_reads_done();
         if (more) ks.issue(j0 + 32);
         float P[16];
         float mt = -INFINITY;
@@ -268,7 +275,7 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
             for (int c = 0; c < NC; ++c) O[c] = MFMA_B(T::tr(Vs, lane, mm, c), Pb[mm], O[c]);
-        asm volatile("" ::: "memory");
+        b_reads_done();
         if (more) vs.issue(j0 + 32);
     };
     if (ntiles == 1) {
@@ -349,7 +356,7 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
         for (int r = 0; r < 16; ++r) dP[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) dP = MFMA_B(T::kc(Vs, l31, half, s), Gr[s], dP);
-        asm volatile("" ::: "memory");
+        b_reads_done();
         if (more) vs.issue(j0 + 32);
         // K(t) (and Q in the first tile); V(t+1) may stay in flight
         if (more) b_wait<PC>();
@@ -378,7 +385,7 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
             for (int c = 0; c < NC; ++c) dQ[c] = MFMA_B(T::tr(Ks, lane, mm, c), Sb[mm], dQ[c]);
-        asm volatile("" ::: "memory");
+        b_reads_done();
         if (more) ks.issue(j0 + 32);
     };
     if (ntiles == 1) {
@@ -479,13 +486,13 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
             for (int c = 0; c < NC; ++c) accK[c] = MFMA_B(T::tr(Qs, lane, mm, c), Sb[mm], accK[c]);          // dK^T += Q^T . dS
-        asm volatile("" ::: "memory");
+        b_reads_done();
         if (more) qs.issue(i0 + 32);
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
             for (int c = 0; c < NC; ++c) accV[c] = MFMA_B(T::tr(Gs, lane, mm, c), Pb[mm], accV[c]);          // dV^T += dO^T . (P o keep)
-        asm volatile("" ::: "memory");
+        b_reads_done();
         if (more) gs.issue(i0 + 32);
     };
     for (int t = 0; t + 1 < nqt; ++t) tile(std::true_type{}, t);

@@ -27,6 +27,7 @@ import torch.distributed as dist
 from torch import nn
 
 from . import _lib
+from . import ops as _ops
 
 
 def get_rank(default: int = 0) -> int:
@@ -269,6 +270,7 @@ class GradBucketReducer:
             return
         self.collectives += 1
         view = self.flat[b["lo"]:b["hi"]]
+        _ops.TwoStream.gather_streams()     # two-stream mode: a bucket holds gradients of both sides; this hook runs on the stream of ONE
         if self.comm is not None:
             ready = torch.cuda.Event()
             ready.record()                                   # on the stream that produced the bucket's last gradient
@@ -497,6 +499,8 @@ class GraphedTrainStep:
             raise RuntimeError("run at least one eager training step before capturing")
         optimizer.zero_grad()
         optimizer.grad_scale = 1.0 / self.world
+        if _ops.get_matmul_precision() == "bf16" and hasattr(optimizer, "bf16_arena"):
+            optimizer.bf16_arena()          # the one-time cast of the whole weight arena happens here, eagerly: not recorded into a graph
         torch.cuda.synchronize()
         flat = optimizer.flat_grad()
         cap = max(1, bucket_bytes // flat.element_size())
@@ -598,8 +602,10 @@ class GraphedTrainStep:
             graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
 
         def phased_backward(loss):
+            from .ops import TwoStream
             cuts = list(enc._cuts)
             loss.backward()
+            TwoStream.join_backward()        # (two-stream mode: every phase's graph ends with the text side joined)
             for _, below, above in reversed(cuts):
                 end_phase()
                 pairs = [(b, a.grad) for b, a in zip(below, above) if a.grad is not None]
@@ -607,6 +613,7 @@ class GraphedTrainStep:
                     a.grad = None
                 if pairs:
                     torch.autograd.backward([b for b, _ in pairs], [g for _, g in pairs])
+                    TwoStream.join_backward()
             enc._cuts = []
 
         torch.cuda.synchronize()

@@ -5,6 +5,7 @@ libytvln.so.  All wrappers require CUDA(HIP) fp32 tensors -- there is no CPU or 
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import ctypes
 import os
@@ -145,6 +146,146 @@ class DropoutState:
         saved = torch.device(key)
         shift = (cur.index or 0) - (saved.index or 0) if saved.type == "cuda" else 0
         cls._global[cur] = torch.tensor([(int(seed) + shift) & 0x7FFFFFFFFFFFFFFF, int(counter)], dtype=torch.int64, device=cur)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# two HIP streams for the two streams of the model
+# ------------------------------------------------------------------------------------------------------------------
+class TwoStream:
+    """The text stream and the image stream of ViLBERT are independent between co-attention layers (vilbert.py:737-811: T0..T5 need
+    nothing from the image side, V_i and T_6+i both start from the outputs of co-layer i, and behind the co-attention itself each side's
+    BertBiOutput + FFN is its own chain).  With `set_two_stream(True)` the text-side launches go to a second HIP stream: the 4480-row
+    text GEMMs fill 82 % of the chip's CUs in their last round of tiles and the small LayerNorm / attention launches of that side leave
+    most of it idle -- the other side's workgroups take those CUs.  Every kernel is still the same deterministic launch and the Python
+    call order (hence every dropout site id) is unchanged, so results are bit-identical to the one-stream run; autograd runs each
+    node's backward on the stream of its forward, so the backward pass splits the same way, and under hipGraph capture the two
+    streams become two branches of the graph.
+
+    Allocator safety: a tensor produced on one stream and read on the other is `record_stream`ed by `side()` / `join()` (gradients
+    crossing streams in the backward pass are recorded by the autograd engine)."""
+
+    enabled = True
+    _side = {}
+    _last_main = {}      # device -> the stream the last region was opened on
+    active = False
+    main = None          # the stream the region was opened on
+    fp = None            # event on the main stream that covers everything the text side may read from it
+
+    @classmethod
+    def side_stream(cls, device) -> "torch.cuda.Stream":
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        s = cls._side.get(device)
+        if s is None:
+            s = cls._side[device] = torch.cuda.Stream(device=device)
+        return s
+
+    @classmethod
+    def begin(cls, device) -> bool:
+        """Start a forked region on the caller's current stream; False when the mode is off or a region is already open."""
+        if not cls.enabled or cls.active or torch.device(device).type != "cuda":
+            return False
+        cls.active = True
+        cls.main = torch.cuda.current_stream()
+        cls._last_main[cls.main.device] = cls.main
+        cls.mark()
+        return True
+
+    @classmethod
+    def mark(cls) -> None:
+        """New fork point: the text side may read whatever the main stream has been given up to here."""
+        if cls.active:
+            ev = torch.cuda.Event()
+            ev.record(cls.main)
+            cls.fp = ev
+
+    @classmethod
+    def side(cls, *inputs):
+        """Context: launches inside go to the side stream, ordered behind the last fork point.  `inputs` = tensors the body reads that
+        were produced on the main stream."""
+        if not cls.active:
+            return contextlib.nullcontext()
+        s = cls.side_stream(cls.main.device)
+        s.wait_event(cls.fp)
+        for t in inputs:
+            if t is not None and t.is_cuda:
+                t.record_stream(s)
+        return torch.cuda.stream(s)
+
+    @classmethod
+    def join(cls, *outs) -> None:
+        """The main stream waits for the text side; `outs` = tensors produced there that the main stream reads next."""
+        if not cls.active:
+            return
+        main = cls.main
+        main.wait_stream(cls.side_stream(main.device))
+        for t in outs:
+            if t is not None and t.is_cuda:
+                t.record_stream(main)
+
+    @classmethod
+    @contextlib.contextmanager
+    def shared_write(cls):
+        """Context for a write to memory that BOTH sides read and that is not part of the forward's dataflow (the lazily created / refreshed
+        bf16 copy of the weight arena): inside a two-stream region the write is enqueued on the main stream, becomes the new fork point,
+        and a caller that is currently on the side stream waits for it too.  Outside a region: a plain pass-through."""
+        if not cls.active:
+            yield
+            return
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(cls.main):
+            yield
+        cls.mark()
+        if cur != cls.main:
+            cur.wait_event(cls.fp)
+
+    @classmethod
+    def gather_streams(cls) -> None:
+        """Make the CURRENT stream wait for both sides of the model.  For code that runs inside a backward pass (a gradient hook runs on the
+        stream of the parameter it fires for) and is about to hand a block of gradients that came from BOTH sides to something ordered
+        behind the current stream only: the bucket collectives of ytvln.distributed."""
+        if not cls.enabled or not cls._side or torch.cuda.is_current_stream_capturing():
+            return
+        cur = torch.cuda.current_stream()
+        for s in (cls._side.get(cur.device), cls._last_main.get(cur.device)):
+            if s is not None and s != cur:
+                cur.wait_stream(s)
+
+    @classmethod
+    def join_backward(cls) -> None:
+        """Call after a backward pass that ran (partly) on the side stream and before anything reads the gradients on the current
+        stream.  The autograd engine joins the streams of the leaves it ran at the end of a backward pass, but a parameter's
+        AccumulateGrad node keeps the stream it was CREATED on: one pinned earlier on the null stream (a post-accumulate hook registered
+        before the model ran) takes no part in a stream capture, and the text side's last kernels would then have no edge to the
+        capturing stream.  This join does not depend on where those nodes live.  No-op when the side stream has nothing in flight for
+        the current capture."""
+        if not cls.enabled or not cls._side or not torch.cuda.is_available():
+            return
+        cur = torch.cuda.current_stream()
+        s = cls._side.get(cur.device)
+        if s is None:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            with torch.cuda.stream(s):
+                if not torch.cuda.is_current_stream_capturing():
+                    return
+        cur.wait_stream(s)
+
+    @classmethod
+    def end(cls, *outs) -> None:
+        cls.join(*outs)
+        cls.active = False
+        cls.fp = cls.main = None
+
+
+def set_two_stream(flag: bool) -> None:
+    """Text-side launches on a second HIP stream (see TwoStream).  Process-wide switch, read at the start of a model forward."""
+    TwoStream.enabled = bool(flag)
+
+
+def get_two_stream() -> bool:
+    return TwoStream.enabled
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -165,8 +165,9 @@ class AdamW(Optimizer):
         if a is None:
             return None
         if a["pb"] is None:
-            a["pb"] = torch.empty(a["p"].numel(), dtype=torch.bfloat16, device=a["p"].device)
-            ops.call("ytvln_cast_f32_bf16", a["p"].data_ptr(), a["p"].numel(), 1, a["p"].numel(), a["pb"].data_ptr(), a["p"].numel(), ops._stream())
+            with ops.TwoStream.shared_write():
+                a["pb"] = torch.empty(a["p"].numel(), dtype=torch.bfloat16, device=a["p"].device)
+                ops.call("ytvln_cast_f32_bf16", a["p"].data_ptr(), a["p"].numel(), 1, a["p"].numel(), a["pb"].data_ptr(), a["p"].numel(), ops._stream())
             a["pb_versions"] = {id(p): p._version for _, p in self._members()}
         vers = a["pb_versions"]
         for p in (params or ()):
@@ -176,7 +177,8 @@ class AdamW(Optimizer):
             if vers.get(id(p)) != p._version:
                 if id(p) in vers:          # modified behind the optimizer's back: refresh this slice
                     o, n = rng
-                    ops.call("ytvln_cast_f32_bf16", a["p"].data_ptr() + 4 * o, n, 1, n, a["pb"].data_ptr() + 2 * o, n, ops._stream())
+                    with ops.TwoStream.shared_write():
+                        ops.call("ytvln_cast_f32_bf16", a["p"].data_ptr() + 4 * o, n, 1, n, a["pb"].data_ptr() + 2 * o, n, ops._stream())
                 vers[id(p)] = p._version
         return a["pb"]
 

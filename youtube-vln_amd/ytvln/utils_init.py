@@ -216,6 +216,7 @@ def train_step(model, optimizer, scheduler, batch, args, step: int = 0, logger=N
         backward(loss)
     else:
         loss.backward()
+    ops.TwoStream.join_backward()       # two-stream mode: the text side's backward kernels before the optimizer reads the gradients
     if not optimizer_step:          # forward/backward only (ytvln.distributed.GraphedTrainStep captures the update separately)
         return loss.detach(), reduced_metrics
     if (step + 1) % accum == 0:

@@ -114,7 +114,18 @@ def _drop_state(module: nn.Module, x: torch.Tensor) -> Optional[DropoutState]:
         return None
     if _Runtime.drop is None:
         _Runtime.drop = DropoutState(x.device)
+        _share_drop_state()
     return _Runtime.drop
+
+
+def _share_drop_state() -> None:
+    """Inside a two-stream region the (seed, counter) tensor of this forward is read by kernels of both HIP streams."""
+    ts = ops.TwoStream
+    if ts.active and _Runtime.drop is not None:
+        t = _Runtime.drop.tensor
+        t.record_stream(ts.side_stream(t.device))
+        if ts.main is not None:
+            t.record_stream(ts.main)
 
 
 def _p(module: nn.Module, p: float) -> float:
@@ -418,14 +429,17 @@ class BertBiAttention(nn.Module):
         # projections' autograd nodes (ops.LinearFn passthrough) so the three gradients meet inside the input-gradient GEMMs
         q1, res1 = ops.linear_res(input_tensor1, self.query1.weight, self.query1.bias)
         kv1, res1 = ops.linear_res(res1, ops.pack_rows(self.key1.weight, self.value1.weight), ops.pack_rows(self.key1.bias, self.value1.bias))
-        q2, res2 = ops.linear_res(input_tensor2, self.query2.weight, self.query2.bias)
-        kv2, res2 = ops.linear_res(res2, ops.pack_rows(self.key2.weight, self.value2.weight), ops.pack_rows(self.key2.bias, self.value2.bias))
+        with ops.TwoStream.side(input_tensor2):         # the text side's projections: second HIP stream when two-stream mode is on
+            q2, res2 = ops.linear_res(input_tensor2, self.query2.weight, self.query2.bias)
+            kv2, res2 = ops.linear_res(res2, ops.pack_rows(self.key2.weight, self.value2.weight), ops.pack_rows(self.key2.bias, self.value2.bias))
+        ops.TwoStream.join(q2, kv2)
         q1, kv1, q2, kv2 = q1.view(n * r, hb), kv1.view(n * r, 2 * hb), q2.view(n * t, hb), kv2.view(n * t, 2 * hb)
         p1, p2 = _p(self, self.dropout1.p), _p(self, self.dropout2.p)
         st = _drop_state(self, q1) if (p1 > 0 or p2 > 0) else None
         s1, s2 = (st.next_site(), st.next_site()) if st else (0, 0)
         ctx1, ctx2, lse1, lse2 = ops.CoAttentionFn.apply(q1, kv1, q2, kv2, m1, m2, n, r, t, self.num_attention_heads, p1, p2,
                                                          st.tensor if st else None, s1, s2)
+        ops.TwoStream.mark()                            # both context tensors exist: the text side may go on from here
         probs = (None, None)
         if self.want_probs:
             with torch.no_grad():
@@ -454,9 +468,11 @@ class BertBiOutput(nn.Module):
 
     def forward(self, hidden_states1, input_tensor1, hidden_states2, input_tensor2):
         c1 = ops.linear(hidden_states1, self.dense1.weight, self.dense1.bias)
-        c2 = ops.linear(hidden_states2, self.dense2.weight, self.dense2.bias)
+        with ops.TwoStream.side(hidden_states2, input_tensor2):
+            c2 = ops.linear(hidden_states2, self.dense2.weight, self.dense2.bias)
         h1 = _add_ln(self.LayerNorm1, c1, input_tensor1, self, p_pre=self.dropout1.p)
-        h2 = _add_ln(self.LayerNorm2, c2, input_tensor2, self, p_pre=self.dropout2.p)
+        with ops.TwoStream.side():
+            h2 = _add_ln(self.LayerNorm2, c2, input_tensor2, self, p_pre=self.dropout2.p)
         return h1, h2
 
 
@@ -477,7 +493,8 @@ class BertConnectionLayer(nn.Module):
         # bi_output2 (image queries over text) feeds the vision stream, bi_output1 the text stream (vilbert.py:671)
         attention_output1, attention_output2 = self.biOutput(bi_output2, res1, bi_output1, res2)
         layer_output1 = _ffn_block(self.v_intermediate, self.v_output, attention_output1)
-        layer_output2 = _ffn_block(self.t_intermediate, self.t_output, attention_output2)
+        with ops.TwoStream.side():
+            layer_output2 = _ffn_block(self.t_intermediate, self.t_output, attention_output2)
         return layer_output1, layer_output2, co_attention_probs
 
 
@@ -524,6 +541,20 @@ class BertEncoder(nn.Module):
         """Interleaving schedule of vilbert.py:737-811: for each (v_id, t_id) pair run the pending image layers, the
         pending text layers, then co-attention layer `count`; finally the remaining layers of both streams."""
         self._set_probs(bool(output_all_attention_masks))
+        ts = ops.TwoStream
+        if self.in_batch_pairs or self.FAST_MODE:
+            ts.end(txt_embedding)                        # these modes rebuild the text rows from the image batch: one stream
+        else:
+            ts.begin(txt_embedding.device)               # (no-op when BertModel.forward opened the region or the mode is off)
+        try:
+            return self._forward(txt_embedding, image_embedding, txt_attention_mask, image_attention_mask, co_attention_mask,
+                                 output_all_encoded_layers, output_all_attention_masks)
+        finally:
+            ts.active = False
+
+    def _forward(self, txt_embedding, image_embedding, txt_attention_mask, image_attention_mask, co_attention_mask,
+                 output_all_encoded_layers, output_all_attention_masks):
+        ts = ops.TwoStream
         v_start = t_start = 0
         all_t, all_v, att_t, att_v, att_c = [], [], [], [], []
         self._cuts = []
@@ -545,7 +576,8 @@ class BertEncoder(nn.Module):
         for count, (v_end, t_end) in enumerate(zip(self.v_biattention_id, self.t_biattention_id)):
             assert self.fixed_t_layer <= t_end and self.fixed_v_layer <= v_end
             image_embedding = run(self.v_layer, v_start, v_end, image_embedding, image_attention_mask, att_v, self.fixed_v_layer, "v")
-            txt_embedding = run(self.layer, t_start, t_end, txt_embedding, txt_attention_mask, att_t, self.fixed_t_layer, "t")
+            with ts.side(txt_embedding, txt_attention_mask):
+                txt_embedding = run(self.layer, t_start, t_end, txt_embedding, txt_attention_mask, att_t, self.fixed_t_layer, "t")
             if count == 0 and self.in_batch_pairs:
                 # every text of the batch against every image of the batch: B -> B^2 rows (vilbert.py:771-778); row (i, j) = text i, image j
                 b, r_, hv = image_embedding.shape
@@ -572,7 +604,9 @@ class BertEncoder(nn.Module):
                 all_t.append(txt_embedding)
                 all_v.append(image_embedding)
         image_embedding = run(self.v_layer, v_start, len(self.v_layer), image_embedding, image_attention_mask, att_v, 0, "v")
-        txt_embedding = run(self.layer, t_start, len(self.layer), txt_embedding, txt_attention_mask, att_t, 0, "t")
+        with ts.side(txt_embedding, txt_attention_mask):
+            txt_embedding = run(self.layer, t_start, len(self.layer), txt_embedding, txt_attention_mask, att_t, 0, "t")
+        ts.end(txt_embedding, *all_t, *(p for p in att_t if p is not None))
         if not output_all_encoded_layers:
             all_t.append(txt_embedding)
             all_v.append(image_embedding)
@@ -804,11 +838,19 @@ class BertModel(BertPreTrainedModel):
             ext_v = ((1.0 - image_attention_mask.to(torch.float32)) * -10000.0).view(nv, 1, 1, r)
         # co_attention_mask only feeds the dead use_co_attention_mask branch (vilbert.py:736): not materialised.
 
-        embedding_output = self.embeddings(input_txt, token_type_ids)
-        v_embedding_output = self.v_embeddings(input_imgs, image_loc)
-        encoded_layers_t, encoded_layers_v, all_attention_mask = self.encoder(
-            embedding_output, v_embedding_output, ext_t, ext_v, None,
-            output_all_encoded_layers=output_all_encoded_layers, output_all_attention_masks=output_all_attention_masks)
+        ts = ops.TwoStream
+        try:
+            if not (self.encoder.in_batch_pairs or self.encoder.FAST_MODE):
+                ts.begin(input_imgs.device)              # two-stream mode: the text side starts at its embeddings
+                _share_drop_state()
+            with ts.side(input_txt, token_type_ids, ext_t):
+                embedding_output = self.embeddings(input_txt, token_type_ids)
+            v_embedding_output = self.v_embeddings(input_imgs, image_loc)
+            encoded_layers_t, encoded_layers_v, all_attention_mask = self.encoder(
+                embedding_output, v_embedding_output, ext_t, ext_v, None,
+                output_all_encoded_layers=output_all_encoded_layers, output_all_attention_masks=output_all_attention_masks)
+        finally:
+            ts.active = False
         sequence_output_t, sequence_output_v = encoded_layers_t[-1], encoded_layers_v[-1]
         pooled_output_t = self.t_pooler(sequence_output_t)
         pooled_output_v = self.v_pooler(sequence_output_v)
