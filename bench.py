@@ -453,7 +453,8 @@ def main():
         ok = control_reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
         if ok:
             step = graph_step
-            how = (f"{len(gs.graphs) + 1} hipGraphs per step (forward + backward in {len(gs.graphs)} phases | AdamW), every phase's gradients all-reduced "
+            how = (f"{len(gs.graphs)} hipGraphs per step (forward + backward in {len(gs.graphs)} phases), every phase's gradients all-reduced and its "
+                   "parameters updated (fused AdamW per group) "
                    + ("on a communication stream under the next phases" if runner.comm is not None else "after its graph, in stream order")) \
                 if (dp_wrap and gs.mode == "phased") else \
                 "two hipGraphs per step (forward+backward | AdamW) with the RCCL all-reduce between them"

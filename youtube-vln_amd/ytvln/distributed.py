@@ -685,27 +685,38 @@ class GraphedTrainStep:
         if not getattr(self, "_verified", False):
             self.verify_layout_across_ranks()
         if self.mode == "phased":
+            # Per phase k: replay its graph on the compute stream; on the communication stream, behind it: all-reduce the gradients that
+            # phase completed, then the fused AdamW update of exactly those parameters (a parameter's last gradient comes from the node that
+            # also reads its weight last, so nothing that still runs touches them).  Both hide under the following phases; what stays
+            # exposed is the last group's exchange and its share of the update.
             cur = torch.cuda.current_stream()
             flat = self.opt.flat_grad()
+            self.opt.prepare_replay()                   # hyper-parameters of this step: uploaded before the first per-group update
+            tables = self.opt.group_tables(self._group_slices, owner=self)
+            overlap = self.comm is not None or not self.exchange          # (torch.distributed data plane: everything in stream order)
             for k, g in enumerate(self.graphs):
                 g.replay()
-                if self.exchange and self._group_slices[k]:
-                    if self.comm is None:       # torch.distributed data plane: same groups, in stream order (no overlap; tests over gloo)
-                        for lo, hi in self._group_slices[k]:
-                            dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-                        continue
-                    self._events[k].record(cur)
-                    self._comm_stream.wait_event(self._events[k])
+                if not self._group_slices[k]:
+                    continue
+                if not overlap:
+                    for lo, hi in self._group_slices[k]:
+                        dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                    self.opt.launch_tables(tables[k])
+                    continue
+                self._events[k].record(cur)
+                self._comm_stream.wait_event(self._events[k])
+                if self.exchange:
                     self.comm.all_reduce_slices(flat, self._group_slices[k], stream=self._comm_stream)
-            if self.exchange and self.comm is not None:
-                if prof:
+                if prof and k == len(self.graphs) - 1:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(cur)
                     e1.record(self._comm_stream)
                     self._prof_events = (e0, e1)
+                with torch.cuda.stream(self._comm_stream):
+                    self.opt.launch_tables(tables[k])
+            if overlap:
                 cur.wait_stream(self._comm_stream)
-            self.opt.prepare_replay()
-            self.graph_b.replay()
+            self.opt.finish_group_step()
             if scheduler is not None:
                 scheduler.step()
             return self.loss

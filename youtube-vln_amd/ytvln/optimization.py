@@ -328,6 +328,57 @@ class AdamW(Optimizer):
                     fg[o:o + n].copy_(p.grad.reshape(-1))
                     p.grad = fg[o:o + n].view(p.shape)
 
+    # -- the update in pieces (ytvln.distributed.GraphedTrainStep, phased): each group of arena ranges is updated as soon as ITS gradients are
+    #    complete and exchanged, on the communication stream, under the rest of the backward pass.  The kernel is element-wise over a chunk
+    #    table, so cutting the table changes no bit.
+    def group_tables(self, group_slices, owner=None):
+        """[per group: [(launch class index, chunk table on the device, number of chunks)]] for groups given as lists of (lo, hi) ranges of
+        the flat arena (whole parameter slots).  Cached on `owner` until the launch classes are rebuilt."""
+        if self._arena is None or self._launch is None:
+            raise RuntimeError("run at least one eager optimizer step first")
+        cache = getattr(owner, "_group_tables_cache", None) if owner is not None else None
+        if cache is not None and cache[0] is self._launch:
+            return cache[1]
+        index, dev = self._arena["index"], self._arena["p"].device
+        starts = sorted((lo, hi, k) for k, sl in enumerate(group_slices) for lo, hi in sl)
+
+        def group_of(o):
+            for lo, hi, k in starts:
+                if lo <= o < hi:
+                    return k
+            return None
+        out = [[] for _ in group_slices]
+        covered = 0
+        for ci, c in enumerate(self._launch):
+            wd = float(self.param_groups[c["group"]]["weight_decay"])
+            recs = [bytearray() for _ in group_slices]
+            counts = [0] * len(group_slices)
+            for p in c["params"]:
+                o, numel = index[id(p)]
+                k = group_of(o)
+                if k is None:
+                    raise RuntimeError("a parameter of the arena belongs to no gradient group: cannot split the update")
+                covered += numel
+                for ch in range(0, numel, CHUNK):
+                    recs[k] += struct.pack("<qqff", o + ch, min(CHUNK, numel - ch), wd, 0.0)
+                    counts[k] += 1
+            for k, rec in enumerate(recs):
+                if counts[k]:
+                    out[k].append((ci, torch.frombuffer(rec, dtype=torch.uint8).to(dev), counts[k]))
+        if owner is not None:
+            owner._group_tables_cache = (self._launch, out)
+        return out
+
+    def launch_tables(self, tables):
+        """The fused AdamW kernels of one group, on the current stream (hyper-parameters come from prepare_replay())."""
+        a = self._arena
+        for ci, table, n in tables:
+            ops.adamw_step(a["p"], a["g"], a["m"], a["v"], table, n, self._launch[ci]["hyper"], self.grad_scale, p_bf16=a["pb"])
+
+    def finish_group_step(self):
+        """After the last group of a step: gradients are consumed, arena slots may be written directly again."""
+        self._written.clear()
+
     def arena_range(self, p):
         """(offset, numel) of a parameter's slot in the flat arenas, or None."""
         return None if self._arena is None else self._arena["index"].get(id(p))
