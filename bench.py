@@ -104,6 +104,63 @@ def make_args(flags):
     return types.SimpleNamespace(**a)
 
 
+class PowerSampler:
+    """Package power and shader clock of the device this rank computes on, read from the hwmon node under its PCI address
+    (/sys/bus/pci/devices/<bdf>/hwmon/*: power1_input in microwatts, freq1_input in Hz, power1_cap) at 20 Hz by a host thread while the timed
+    steps run.  Says on which side of the power limit a run was taken (the fp32 GEMMs lose 15 % on boxes that hold the chip below ~1.2 kW and
+    nothing on boxes that do not; LABNOTES 5b).  None when the container does not expose the node."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.hw = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            nodes = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            self.hw = nodes[0] if nodes else None
+        except Exception:
+            self.hw = None
+        self.p, self.f, self.on = [], [], False
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.hw else None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.hw, name)) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while self.on:
+            p, f = self._read("power1_input"), self._read("freq1_input")
+            if p is not None:
+                self.p.append(p / 1e6)
+            if f is not None:
+                self.f.append(f / 1e6)
+            time.sleep(0.05)
+
+    def start(self):
+        if self._thread is not None:
+            self.on = True
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self.on = False
+        self._thread.join()
+        cap = self._read("power1_cap")
+        out = {"source": self.hw + "/power1_input, freq1_input (20 Hz over the timed steps)", "samples": len(self.p)}
+        if self.p:
+            out.update(mean_w=round(sum(self.p) / len(self.p), 1), max_w=round(max(self.p), 1))
+        if cap is not None:
+            out["cap_w"] = round(cap / 1e6, 1)
+        if self.f:
+            out.update(sclk_mhz_mean=round(sum(self.f) / len(self.f), 1), sclk_mhz_min=round(min(self.f), 1))
+        return out
+
+
 class GemmTimer:
     """Brackets every GEMM launch with HIP events on the launch stream (torch's current stream = the stream the C ABI is
     given) and sums algorithmic FLOPs; read out after the timed region."""
@@ -525,6 +582,9 @@ def main():
         for i in range(2):                         # the upload / assembly buffers are new: let the allocator settle before timing
             step(a.warmup + i)
         torch.cuda.synchronize()
+    power = PowerSampler(dev) if rank == 0 else None
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     c0 = time.thread_time()
     pc0 = time.process_time()
@@ -540,6 +600,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    power_info = power.stop() if power is not None else None
     host_cpu_process = time.process_time() - pc0     # every thread of this rank until the steps have drained: + RCCL proxy / HIP runtime threads
     timer.on = ftimer.on = False
     elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)
@@ -670,6 +731,7 @@ def main():
         "host_enqueue_ms_tail": {"p50": round(1000.0 * float(np.percentile(enq, 50)), 2), "max": round(1000.0 * max(enq), 2)},   # per step, this rank
         "host_cores_available": effective_cores(),
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
+        "power": power_info,
     }
     if host_probe is not None:
         out["host_probe"] = host_probe
