@@ -167,6 +167,7 @@ class TwoStream:
     enabled = True
     _side = {}
     _last_main = {}      # device -> the stream the last region was opened on
+    _quiet = False
     active = False
     main = None          # the stream the region was opened on
     fp = None            # event on the main stream that covers everything the text side may read from it
@@ -186,6 +187,13 @@ class TwoStream:
         """Start a forked region on the caller's current stream; False when the mode is off or a region is already open."""
         if not cls.enabled or cls.active or torch.device(device).type != "cuda":
             return False
+        if not cls._quiet:
+            # a parameter both sides use (the word embedding tied to the language decoder) gets gradients from both streams by design: the
+            # engine orders them; its advice to "initialise DDP under the same stream" does not apply
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
+            cls._quiet = True
         cls.active = True
         cls.main = torch.cuda.current_stream()
         cls._last_main[cls.main.device] = cls.main
