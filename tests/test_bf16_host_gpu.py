@@ -193,3 +193,34 @@ def test_inference_rerank_shapes_bf16_against_fp32(dev, lib):
         top2 = torch.topk(ra[v], 2).values
         if float(top2[0] - top2[1]) > 4e-2 * max(spread, 1.0):
             assert int(torch.argmax(ra[v])) == int(torch.argmax(rb[v]))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_model_backward_is_bit_reproducible(dev, lib, precision):
+    """The FULL model at BASELINE configs[3] size (96 rows, R = 252, T = 80: ~20 000 one-wave attention workgroups per layer), forward +
+    backward three times on the same weights and batch, dropout off: losses and EVERY gradient must come out bit-identical (all reductions
+    have a fixed order; two HIP streams do not change that).  This is the test that would have caught the write-after-read race on the LDS
+    tile buffers of the bf16 attention kernels, which the golden's 5 % gradient-norm bars let through five times in six."""
+    from ytvln import ops, synth
+    from test_model_gpu import FULL_CFG
+    args = args_ns(ranking=True, pretrain=False, num_negatives=2)
+    model, _ = build_lily(dev, FULL_CFG, args, seed=33)
+    batch = synth.to_torch(synth.make_batch(bs=16, K=6, T=80, frames=7, boxes=36, seed=43, finetune_heading=True), dev)
+    model.train()
+    ops.set_matmul_precision(precision)
+    runs = []
+    try:
+        for i in range(3):
+            model.zero_grad(set_to_none=True)
+            junk = torch.full((96 * 252, 1024), 3.0, device=dev)      # fresh activations do not land on the last run's values
+            del junk
+            _, total, _ = losses_of(model, batch, args)
+            total.backward()
+            torch.cuda.synchronize()
+            runs.append((float(total), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        ops.set_matmul_precision("fp32")
+    for i in (1, 2):
+        assert runs[i][0] == runs[0][0], (i, runs[i][0], runs[0][0])
+        bad = [(n, float((g - runs[0][1][n]).abs().max())) for n, g in runs[i][1].items() if not torch.equal(g, runs[0][1][n])]
+        assert not bad, (i, bad[:6])
