@@ -19,16 +19,15 @@ def wrapped(*a, **k):
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
             out = real(*a, **k)
             torch.cuda.synchronize()
-        agg = collections.Counter(); tim = collections.Counter()
-        for ev in prof.events():
-            if ev.device_type == torch.autograd.DeviceType.CPU and ev.name.startswith("aten::") and ev.name.split("::")[1] in (
-                    "copy_", "fill_", "zero_", "cat", "add", "add_", "mul", "mul_", "sum", "to", "_to_copy", "clone", "contiguous", "div", "sub", "rsub", "index", "masked_fill", "eq", "ne", "where"):
-                stack = [s for s in ev.stack if "ytvln" in s or "bench.py" in s]
-                key = (ev.name, stack[0].strip()[-90:] if stack else "?")
-                agg[key] += 1
-                tim[key] += ev.device_time_total if hasattr(ev, "device_time_total") else 0
-        for (name, where), n in agg.most_common(60):
-            print(f"{n:5d}  {name:18s} {tim[(name, where)]:9.1f} us  {where}", file=sys.stderr)
+        rows = []
+        for ev in prof.key_averages(group_by_stack_n=8):
+            if ev.key.startswith("aten::") and ev.key.split("::")[1] in (
+                    "copy_", "fill_", "zero_", "cat", "add", "add_", "mul", "mul_", "sum", "div", "sub", "rsub", "eq", "masked_fill", "where", "index", "neg", "clamp"):
+                stack = [s_ for s_ in ev.stack if ("ytvln" in s_ or "bench.py" in s_) and "native_ops" not in s_]
+                rows.append((ev.count, ev.key, ev.device_time_total, " <- ".join(x.strip().split("/")[-1][:70] for x in stack[:3]) or "?"))
+        rows.sort(key=lambda r: -r[0])
+        for n, name, t, where in rows[:50]:
+            print(f"{n:5d}  {name:14s} {t:9.1f} us  {where}", file=sys.stderr)
         return out
     return real(*a, **k)
 utils_init.train_step = wrapped
