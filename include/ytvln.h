@@ -90,6 +90,28 @@ int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, const float* 
                           float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done,
                           void* stream);
 
+/* The same projection with the PERSISTENT kernel available (csrc/gemm_sk.hip; the nn.Linear forward and input-gradient GEMMs of
+ * vilbert.py:285-287, 322, 352, 365, 555-568, 641-644 with a K-contiguous A): one workgroup per CU walks whole output tiles or --
+ * stream-K form -- an equal share of the (tile, k-tile) iteration space, the next piece's operands in flight under the epilogue; partial
+ * tiles are added in ascending k order by the workgroup that holds the k = 0 end of the tile (bit-reproducible).
+ *   sk_ctl: ytvln_gemm_sk_ctl_elems() uint32 words, ZERO when first used and private to the stream the call is enqueued on (the kernel
+ *   leaves it zero); NULL = exactly ytvln_gemm_f32 / ytvln_gemm_f32_rowsum.  workspace (ytvln_gemm_workspace_elems) also holds the
+ *   partial tiles.  a_rowsum / rowsum_done: both NULL or both set (as ytvln_gemm_f32_rowsum).  The launch planner decides per shape between
+ *   this kernel and the launch-per-tile one (run-time options GEMM_SK, GEMM_SK_TILE, GEMM_SK_GROUPS, GEMM_KROT). */
+int64_t ytvln_gemm_sk_ctl_elems(void);
+int ytvln_gemm_f32_sk(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                      int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,
+                      float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done,
+                      uint32_t* sk_ctl, void* stream);
+/* Introspection (host only): does the planner take the persistent kernel for this aligned problem, with which tile, in the whole-tile
+ * (*whole_tiles = 1) or the stream-K form, on how many workgroups. */
+int ytvln_gemm_sk_plan(int M, int N, int K, int transA, int epilogue, int* use, int* tile_m, int* tile_n, int* whole_tiles,
+                       int* workgroups);
+/* Diagnostics: when `buffer` is non-NULL every workgroup of a persistent launch writes 16 s_memrealtime stamps (100 MHz) to
+ * buffer[16 * workgroup + i]: 0 start, 1 ticket drawn, 2 first operands in LDS, then (main loop done, epilogue issued) per piece, 15 end.
+ * The buffer must hold 16 * 256 uint64; NULL switches the stamps off (default). */
+int ytvln_gemm_probe(unsigned long long* buffer);
+
 /* out[b, n] = sum over the b-th block of `rows_per_block` rows of x[:, n].  out is [ceil(M/rows_per_block), N] with
  * leading dimension ldo (bias gradients, position-embedding gradient, second stage of every column reduction). */
 int ytvln_colsum_f32(const float* x, int64_t ldx, int M, int N, float* out, int64_t ldo, int rows_per_block,

@@ -1,0 +1,70 @@
+"""Persistent / stream-K fp32 GEMM against the launch-per-tile kernel, per cfg-2 shape (HIP events, ITERS launches each), and the
+in-kernel timeline of one launch (ytvln_gemm_probe: 16 stamps per workgroup at 100 MHz).  SHAPES=img|text|all, PROBE=1 for timelines."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd"))
+import numpy as np
+import torch
+from ytvln import ops, _lib
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+IMG = [(16128, 1024, 1024, 1), (16128, 1024, 1024, 0), (16128, 3072, 1024, 1), (16128, 1024, 3072, 0), (16128, 2048, 1024, 1), (16128, 1024, 2048, 0)]
+TEXT = [(4480, 3072, 768, 1), (4480, 768, 3072, 1), (4480, 3072, 768, 0), (4480, 768, 3072, 0), (4480, 2304, 768, 1), (4480, 768, 2304, 0),
+        (4480, 768, 768, 1), (4480, 30528, 768, 1)]
+which = os.environ.get("SHAPES", "all")
+shapes = {"img": IMG, "text": TEXT, "all": IMG + TEXT}[which]
+ITERS = int(os.environ.get("ITERS", "20"))
+CONFIGS = [("old", dict(GEMM_SK=0)), ("dp4", dict(GEMM_SK=2, GEMM_SK_TILE=4)), ("sk4", dict(GEMM_SK=3, GEMM_SK_TILE=4)),
+           ("dp3", dict(GEMM_SK=2, GEMM_SK_TILE=3)), ("sk3", dict(GEMM_SK=3, GEMM_SK_TILE=3)),
+           ("dp4r1", dict(GEMM_SK=2, GEMM_SK_TILE=4, GEMM_KROT=1)), ("dp4r3", dict(GEMM_SK=2, GEMM_SK_TILE=4, GEMM_KROT=3)),
+           ("sk4r3", dict(GEMM_SK=3, GEMM_SK_TILE=4, GEMM_KROT=3)), ("sk4g1", dict(GEMM_SK=3, GEMM_SK_TILE=4, GEMM_SK_GROUPS=1))]
+if os.environ.get("CONFIGS"):
+    CONFIGS = [c for c in CONFIGS if c[0] in os.environ["CONFIGS"].split(",")]
+DEFAULTS = dict(GEMM_SK=1, GEMM_SK_TILE=-1, GEMM_KROT=0, GEMM_SK_GROUPS=8)
+
+
+def setopts(d):
+    for k, v in {**DEFAULTS, **d}.items():
+        _lib.set_option(k, v)
+
+
+def timed(fn, iters=ITERS):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1000
+
+
+probe = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
+for (M, N, K, tb) in shapes:
+    A = torch.randn(M, K, device=dev)
+    B = torch.randn((N, K) if tb else (K, N), device=dev)
+    C = torch.empty(M, N, device=dev)
+    go = lambda: ops._gemm(A, K, 0, B, B.stride(0), tb, C, N, M, N, K)
+    line = f"{M:6d} {N:6d} {K:5d} tB{tb} "
+    for name, o in CONFIGS:
+        setopts(o)
+        us = timed(go)
+        line += f" {name} {us:7.1f}us {2.0 * M * N * K / us / 1e6:6.1f}TF |"
+    print(line, flush=True)
+    if os.environ.get("PROBE"):
+        for name, o in CONFIGS:
+            if name == "old": continue
+            setopts(o)
+            go(); torch.cuda.synchronize()
+            lib.ytvln_gemm_probe(ctypes.c_void_p(probe.data_ptr()))
+            probe.zero_(); torch.cuda.synchronize()
+            go(); torch.cuda.synchronize()
+            lib.ytvln_gemm_probe(None)
+            p = probe.view(256, 16).cpu().numpy().astype(np.float64) / 100.0      # us
+            t0 = p[:, 0].min()
+            start, tick, first, end = p[:, 0] - t0, p[:, 1] - p[:, 0], p[:, 2] - p[:, 1], p[:, 15] - t0
+            pm, pe = p[:, 3] - p[:, 2], p[:, 4] - p[:, 3]           # first piece: main loop, epilogue issue
+            has2 = p[:, 5] > 0
+            print(f"   probe {name}: start spread {start.max():5.1f}  ticket {tick.mean():4.1f}/{tick.max():4.1f}  first operands {first.mean():4.1f}/{first.max():4.1f}"
+                  f"  piece0 main {pm.mean():6.1f}/{pm.max():6.1f} epi {pe.mean():5.1f}/{pe.max():5.1f}"
+                  + (f"  piece1 main {(p[has2, 5] - p[has2, 4]).mean():6.1f} epi {(p[has2, 6] - p[has2, 5]).mean():5.1f}" if has2.any() else "")
+                  + f"  end min/mean/max {end.min():6.1f}/{end.mean():6.1f}/{end.max():6.1f}", flush=True)
+setopts({})

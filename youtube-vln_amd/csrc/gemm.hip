@@ -496,13 +496,16 @@ extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue)
                                 1);
     // (covers either A layout and the fp32x3 plans)
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
+    // the stream-K form of the persistent kernel (K-contiguous A): one partial tile per workgroup
+    // (sized for either tile and independent of the run-time options, so a caller may cache the figure)
+    if (M >= 256 && N >= 128) need = std::max<int64_t>(need, (int64_t)sk_num_cus() * 256 * (N >= 256 ? 256 : 128));
     return need;
 }
 
 static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                          int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
                          int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done,
-                         void* stream) {
+                         unsigned* sk_ctl, void* stream) {
     if (rowsum_done) *rowsum_done = 0;
     YT_REQUIRE(A && B && C, "gemm: null operand");
     YT_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative size");
@@ -538,6 +541,16 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     const bool ta_native = g.fast && transA && !g.x3;
     Plan plan = plan_gemm(M, N, K, epilogue, g.fast, g.x3 && g.fast, ta_native);
     const int want = plan.splits;
+    // persistent kernel (gemm_sk.hip): needs the caller's zero-initialised control block; taken when its model cost beats the launch-per-tile plan
+    if (sk_ctl && !a_rowsum) {
+        SkPlan sp = plan_sk(M, N, g.Kloop, transA, epilogue, g.fast, g.x3 != 0);
+        if (sp.use && !sp.dp && (!workspace || workspace_elems < sk_workspace_elems(sp))) sp.use = 0;
+        if (sp.use && (opt(OPT_GEMM_SK) >= 2 || sp.cost < 0.98 * plan_cost(M, N, K, plan.tile, plan.splits, epilogue, false, ta_native))) {
+            sk_launch(g, sp, transB, workspace, sk_ctl, s);
+            YT_LAUNCH_CHECK("gemm_f32 (persistent)");
+            return 0;
+        }
+    }
     // row sums of op(A) ride on launches that take the LDS-DMA main loop with an M-contiguous fp32 A and no K tail (a clamped tail row would
     // be counted twice); everything else reports "not done" and the caller runs ytvln_colsum_f32
     const bool asum_ok = a_rowsum && g.fast && transA && !g.x3 && !g.ktail && K % BK == 0;
@@ -580,7 +593,7 @@ extern "C" int ytvln_gemm_f32(const float* A, int64_t lda, int transA, const flo
                               int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
                               int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, void* stream) {
     return gemm_f32_impl(A, lda, transA, B, ldb, transB, C, ldc, bias, aux, ldaux, M, N, K, epilogue, beta, workspace, workspace_elems, flags,
-                         nullptr, nullptr, stream);
+                         nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
@@ -589,7 +602,26 @@ extern "C" int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, co
                                      int* rowsum_done, void* stream) {
     YT_REQUIRE(a_rowsum && rowsum_done, "gemm_f32_rowsum: null row-sum output");
     return gemm_f32_impl(A, lda, transA, B, ldb, transB, C, ldc, bias, aux, ldaux, M, N, K, epilogue, beta, workspace, workspace_elems, flags,
-                         a_rowsum, rowsum_done, stream);
+                         a_rowsum, rowsum_done, nullptr, stream);
+}
+
+extern "C" int ytvln_gemm_f32_sk(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                                 int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K,
+                                 int epilogue, float beta, float* workspace, int64_t workspace_elems, int flags, float* a_rowsum,
+                                 int* rowsum_done, uint32_t* sk_ctl, void* stream) {
+    YT_REQUIRE((a_rowsum == nullptr) == (rowsum_done == nullptr), "gemm_f32_sk: a_rowsum and rowsum_done go together");
+    return gemm_f32_impl(A, lda, transA, B, ldb, transB, C, ldc, bias, aux, ldaux, M, N, K, epilogue, beta, workspace, workspace_elems, flags,
+                         a_rowsum, rowsum_done, sk_ctl, stream);
+}
+
+extern "C" int ytvln_gemm_sk_plan(int M, int N, int K, int transA, int epilogue, int* use, int* tile_m, int* tile_n, int* whole_tiles,
+                                  int* workgroups) {
+    YT_REQUIRE(use && tile_m && tile_n && whole_tiles && workgroups && M > 0 && N > 0 && K > 0, "gemm_sk_plan: bad argument");
+    const SkPlan sp = plan_sk(M, N, (int)cdiv(K, BK) * BK, transA, epilogue, true, false);
+    const Plan plan = plan_gemm(M, N, K, epilogue, true, false, transA != 0);
+    *use = sp.use && (opt(OPT_GEMM_SK) >= 2 || sp.cost < 0.98 * plan_cost(M, N, K, plan.tile, plan.splits, epilogue, false, transA != 0));
+    *tile_m = 256; *tile_n = sp.tile == 4 ? 256 : 128; *whole_tiles = sp.dp; *workgroups = sp.G;
+    return 0;
 }
 
 #endif  // YT_GEMM_X3_TU

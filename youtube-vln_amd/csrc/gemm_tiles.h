@@ -269,4 +269,11 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 
+// ---- persistent / stream-K kernel (gemm_sk.hip) -------------------------------------------------------------------------------------
+struct SkPlan { int use; int tile; int dp; int G; int ngroups; double cost; };       // tile: 3 = 256x128, 4 = 256x256; cost: model estimate, us
+SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, bool x3);
+int sk_num_cus();
+int64_t sk_workspace_elems(const SkPlan& p);                                          // floats of partial-tile scratch (0 for the whole-tile form)
+void sk_launch(GemmArgs& g, const SkPlan& p, int transB, float* partials, unsigned* ctl, hipStream_t s);
+
 }  // namespace ytvln

@@ -34,6 +34,10 @@ SIGNATURES = {
     "ytvln_gemm_workspace_elems": [I32, I32, I32, I32],
     "ytvln_gemm_f32": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P],
     "ytvln_gemm_f32_rowsum": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P, P, P],
+    "ytvln_gemm_sk_ctl_elems": [],
+    "ytvln_gemm_f32_sk": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P, P, P, P],
+    "ytvln_gemm_sk_plan": [I32, I32, I32, I32, I32, P, P, P, P, P],
+    "ytvln_gemm_probe": [P],
     "ytvln_colsum_f32": [P, I64, I32, I32, P, I64, I32, P],
     "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
     "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],
@@ -94,7 +98,7 @@ SIGNATURES = {
     "ytvln_rccl_async_error": [P],
     "ytvln_rccl_destroy": [P],
 }
-RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
+RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_gemm_sk_ctl_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
 DT_F32, DT_F64, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128

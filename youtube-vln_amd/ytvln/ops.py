@@ -337,17 +337,37 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
     need = _WS_CACHE.get(key)
     if need is None:
         need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, K, epi))
-    ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K scratch (caching allocator)
+    ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K / stream-K scratch (caching allocator)
     if _MATMUL_PRECISION == "fp32x3":
         flags = int(flags) | GEMM_SPLIT_BF16X3
+    ctl = _sk_ctl(C.device)
     if rowsum is not None:
         done = ctypes.c_int(0)
-        call("ytvln_gemm_f32_rowsum", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
-             M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _ptr(rowsum), ctypes.byref(done), _stream())
+        call("ytvln_gemm_f32_sk", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
+             M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _ptr(rowsum), ctypes.byref(done), _ptr(ctl), _stream())
         return bool(done.value)
-    call("ytvln_gemm_f32", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
-         M, N, K, epi, float(beta), _ptr(ws), need, int(flags), _stream())
+    call("ytvln_gemm_f32_sk", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
+         M, N, K, epi, float(beta), _ptr(ws), need, int(flags), None, None, _ptr(ctl), _stream())
     return False
+
+
+_SK_CTL = {}
+
+
+def _sk_ctl(device):
+    """Control block of the persistent GEMM (ytvln_gemm_f32_sk: tickets, done counters, partial-tile flags; zero between launches).  A block
+    must never be shared by two launches that can run at the same time, so there is one per device and ROLE: the side stream of
+    `TwoStream` and everything else (eager, captured and replayed launches of a role are ordered among themselves).  Created outside
+    stream capture; a first use inside a capture gets None = the launch-per-tile kernel."""
+    pair = _SK_CTL.get(device)
+    if pair is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        n = int(_lib.load().ytvln_gemm_sk_ctl_elems())
+        pair = _SK_CTL[device] = (torch.zeros(n, dtype=torch.int32, device=device), torch.zeros(n, dtype=torch.int32, device=device))
+        torch.cuda.synchronize(device)
+    side = TwoStream._side.get(device)
+    return pair[1] if (side is not None and _stream() == side.cuda_stream) else pair[0]
 
 
 def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> Tensor:
