@@ -97,7 +97,7 @@ int ytvln_gemm_f32_rowsum(const float* A, int64_t lda, int transA, const float* 
  *   sk_ctl: ytvln_gemm_sk_ctl_elems() uint32 words, ZERO when first used and private to the stream the call is enqueued on (the kernel
  *   leaves it zero); NULL = exactly ytvln_gemm_f32 / ytvln_gemm_f32_rowsum.  workspace (ytvln_gemm_workspace_elems) also holds the
  *   partial tiles.  a_rowsum / rowsum_done: both NULL or both set (as ytvln_gemm_f32_rowsum).  The launch planner decides per shape between
- *   this kernel and the launch-per-tile one (run-time options GEMM_SK, GEMM_SK_TILE, GEMM_SK_GROUPS, GEMM_KROT). */
+ *   this kernel and the launch-per-tile one (run-time options GEMM_SK, GEMM_SK_TILE, GEMM_SK_GROUPS). */
 int64_t ytvln_gemm_sk_ctl_elems(void);
 int ytvln_gemm_f32_sk(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                       int64_t ldc, const float* bias, float* aux, int64_t ldaux, int M, int N, int K, int epilogue,

@@ -106,21 +106,6 @@ def test_persistent_gemm_every_tile_right(dev, lib, M, N, K, tb, epi, form, tile
         assert _ctl_zero(dev)
 
 
-@pytest.mark.parametrize("krot", [1, 2, 5])
-def test_persistent_gemm_k_rotation(dev, lib, krot):
-    """A rotated start of the contraction is another summation order of the same products."""
-    from ytvln import ops
-    M, N, K = 4480, 3072, 768
-    A, W = _rand(dev, M, K, seed=1), _rand(dev, N, K, seed=2)
-    ref = A.double() @ W.double().t()
-    for form in (2, 3):
-        C = torch.empty(M, N, device=dev)
-        with _Opts(GEMM_SK=form, GEMM_KROT=krot):
-            ops._gemm(A, K, 0, W, K, 1, C, N, M, N, K)
-        assert float(_tile_errors(C, ref).max()) < 4e-6 * math.sqrt(K) + 1e-6
-    assert _ctl_zero(dev)
-
-
 def test_persistent_gemm_zero_padded_k_tail(dev, lib):
     """dX of the 30522-wide decoder (vilbert.py:906 backward): K = 30522 with A's K tail zero padded, B's k rows clamped."""
     from ytvln import ops

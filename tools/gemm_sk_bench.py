@@ -15,11 +15,10 @@ shapes = {"img": IMG, "text": TEXT, "all": IMG + TEXT}[which]
 ITERS = int(os.environ.get("ITERS", "20"))
 CONFIGS = [("old", dict(GEMM_SK=0)), ("dp4", dict(GEMM_SK=2, GEMM_SK_TILE=4)), ("sk4", dict(GEMM_SK=3, GEMM_SK_TILE=4)),
            ("dp3", dict(GEMM_SK=2, GEMM_SK_TILE=3)), ("sk3", dict(GEMM_SK=3, GEMM_SK_TILE=3)),
-           ("dp4r1", dict(GEMM_SK=2, GEMM_SK_TILE=4, GEMM_KROT=1)), ("dp4r3", dict(GEMM_SK=2, GEMM_SK_TILE=4, GEMM_KROT=3)),
-           ("sk4r3", dict(GEMM_SK=3, GEMM_SK_TILE=4, GEMM_KROT=3)), ("sk4g1", dict(GEMM_SK=3, GEMM_SK_TILE=4, GEMM_SK_GROUPS=1))]
+           ("old4", dict(GEMM_SK=0, GEMM_TILE=4)), ("old0", dict(GEMM_SK=0, GEMM_TILE=0)), ("sk4g1", dict(GEMM_SK=3, GEMM_SK_TILE=4, GEMM_SK_GROUPS=1))]
 if os.environ.get("CONFIGS"):
     CONFIGS = [c for c in CONFIGS if c[0] in os.environ["CONFIGS"].split(",")]
-DEFAULTS = dict(GEMM_SK=1, GEMM_SK_TILE=-1, GEMM_KROT=0, GEMM_SK_GROUPS=8)
+DEFAULTS = dict(GEMM_SK=1, GEMM_SK_TILE=-1, GEMM_SK_GROUPS=8, GEMM_TILE=-1)
 
 
 def setopts(d):
@@ -51,7 +50,7 @@ for (M, N, K, tb) in shapes:
     print(line, flush=True)
     if os.environ.get("PROBE"):
         for name, o in CONFIGS:
-            if name == "old": continue
+            if name.startswith("old"): continue
             setopts(o)
             go(); torch.cuda.synchronize()
             lib.ytvln_gemm_probe(ctypes.c_void_p(probe.data_ptr()))

@@ -42,7 +42,6 @@ enum Option {
     OPT_GEMM_SK,             // persistent fp32 GEMM (gemm_sk.hip): 1 (default) the planner decides, 0 never, 2 whole-tile (DP) form wherever legal, 3 stream-K form wherever legal
     OPT_GEMM_SK_TILE,        // -1 (default): planner; 3 / 4 forces 256x128 / 256x256 tiles for the persistent kernel
     OPT_GEMM_SK_GROUPS,      // 8 (default): one ticket group per XCD; 1: one group over the whole launch (partial tiles may cross XCDs)
-    OPT_GEMM_KROT,           // persistent kernel: tile t starts its contraction at k-tile (t * KROT) % nk (default 0 = every tile at k = 0)
     OPT_COUNT
 };
 int opt(int id);

@@ -23,10 +23,9 @@ namespace ytvln {
 
 struct SkArgs {
     int G, ngroups, gsize;      // workgroups in the launch, ticket groups, workgroups per group
+    int gshift;                 // log2(gsize) when gsize is a power of two, else -1
     int nk;                     // k-tiles per output tile
     int dp;                     // 1: whole tiles only (tile r, r + gsize, ... of the group), 0: stream-K ranges
-    int krot;                   // k rotation: tile t starts its contraction at k-tile (t * krot) % nk (spreads the operand rows the workgroups of a
-                                // launch read at the same time over the memory channels); 0 = every tile starts at k = 0
     int tile_begin[9];          // group x owns tiles [tile_begin[x], tile_begin[x + 1]) of the grouped tile order
     float* partials;            // [G][slot]: slot = one accumulator dump in fragment order (NW * 64 lanes x 16 * TM * TN floats)
     unsigned* ctl;              // zero-initialised: [0, 8) tickets, [8, 16) done counters, [16, 16 + G) partial-ready flags
@@ -35,13 +34,29 @@ struct SkArgs {
 
 constexpr int SK_CTL_TICKET = 0, SK_CTL_DONE = 8, SK_CTL_FLAG = 16;
 
+// range r of a group's iteration space [0, I = tiles x k-tiles): [floor(I r / gsize), floor(I (r + 1) / gsize)).  32-bit arithmetic (the host
+// checks I * gsize < 2^31): a 64-bit division is a ~130-instruction VALU routine that made hipcc spill all 128 accumulators around it.
 __device__ __forceinline__ void sk_range(const SkArgs& sk, int r, int ntg, int& s, int& e) {
-    const long long I = (long long)ntg * sk.nk;
-    s = (int)(I * r / sk.gsize);
-    e = (int)(I * (r + 1) / sk.gsize);
+    const unsigned I = (unsigned)ntg * (unsigned)sk.nk;
+    if (sk.gshift >= 0) { s = (int)((I * (unsigned)r) >> sk.gshift); e = (int)((I * (unsigned)(r + 1)) >> sk.gshift); }
+    else { s = (int)(I * (unsigned)r / (unsigned)sk.gsize); e = (int)(I * (unsigned)(r + 1) / (unsigned)sk.gsize); }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB>
+// 16-byte write-through store (sc1: visible to every XCD once acknowledged, no release fence needed): scalar base + per-lane byte offset
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(uint32_t voff, f32x4 v, const void* sbase) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+__device__ __forceinline__ void load16(f32x4& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait16(f32x4 (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, bool SK>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, const SkArgs sk) {
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
@@ -62,26 +77,30 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
     unsigned long long* probe = sk.probe ? sk.probe + (size_t)bid * 16 : nullptr;
     int pidx = 0;
     auto stamp = [&]() {
-        if (probe && tid == 0 && pidx < 16) probe[pidx] = __builtin_amdgcn_s_memrealtime();
+        if (probe && tid == 0 && pidx < 15) probe[pidx] = __builtin_amdgcn_s_memrealtime();
         ++pidx;
     };
     stamp();                                                              // [0] start
 
-    // ---- ticket -> range ------------------------------------------------------------------------------------------------------------
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(sk.ctl + SK_CTL_TICKET + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<volatile int*>(smem)[NS * STAGE] = (int)t;
+    // ---- place in the range order: stream-K draws a ticket (see the header), whole-tile launches wait for nobody and use the block id ------
+    int r;
+    if constexpr (!SK) {
+        r = bid / sk.ngroups;
+    } else {
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(sk.ctl + SK_CTL_TICKET + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            reinterpret_cast<volatile int*>(smem)[NS * STAGE] = (int)t;
+        }
+        __syncthreads();
+        r = sk.gsize - 1 - __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile int*>(smem)[NS * STAGE]);      // descending with the ticket
     }
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile int*>(smem)[NS * STAGE]);
-    const int r = sk.gsize - 1 - ticket;                                  // range index inside the group (descending with the ticket)
     const int tb = sk.tile_begin[group], ntg = sk.tile_begin[group + 1] - tb;
     const int nk = sk.nk;
     const int my_slot = group * sk.gsize + r;
-    stamp();                                                              // [1] ticket drawn
+    stamp();                                                              // [1] range known
 
     int c_tile, c_k, c_rem, tile_step;
-    if (sk.dp) {
+    if constexpr (!SK) {
         tile_step = sk.gsize;
         c_tile = r; c_k = 0;
         c_rem = r < ntg ? ((ntg - r + sk.gsize - 1) / sk.gsize) * nk : 0;
@@ -92,35 +111,49 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
         c_tile = s / nk; c_k = s - c_tile * nk; c_rem = e - s;
     }
     int c_k0 = c_k;
-    int i_tile = c_tile, i_k = c_k, i_rem = c_rem;
-    bool i_new = true;
+    // a stream-K range that ends inside a tile owns that tile's HEAD: the partial tiles to add are those of ranges r + 1 .. jend - 1 (every range
+    // is non-empty: the host checks it).  Worked out here, before the accumulators are live: any division or loop nest between the main loop and
+    // the epilogue made hipcc spill all 128 of them.
+    int jend = r + 1;
+    if (SK && c_rem > 0) {
+        int s, e;
+        sk_range(sk, r, ntg, s, e);
+        int kk = e % nk;                          // k-tiles of the last tile this range covers (0: it ends on a tile boundary)
+        if (kk > 0 && e - s >= kk) {              // ... and it holds that tile's k = 0 end
+            while (kk < nk) {
+                int s2, e2;
+                sk_range(sk, jend, ntg, s2, e2);
+                kk += min(e2 - s2, nk - kk);
+                ++jend;
+            }
+        }
+    }
+    int i_tile = c_tile, i_k = c_k, i_rem = c_rem;        // issue cursor: one k-tile ahead of the compute cursor, across piece boundaries
 
     const float* pa[TA::NI];
     const float* pb[TB::NI];
     const int64_t sa = TA::step(g.lda), sb = TB::step(g.ldb);
-    int kp = 0;                                                           // physical k-tile of the next issue
     int st_in = 0, st_out = 0;
 
+    // per-lane source pointers of the k-tile the issue cursor stands on (rebuilt from scalars at every tile change AND behind every epilogue, so
+    // that no address register has to survive the epilogue next to the accumulators)
+    auto setup_ptrs = [&]() {
+        const TileCoord tc = tile_coord(tb + i_tile, g.tiles_m, g.tiles_n);
+#pragma unroll
+        for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, tc.m * BM, i_k * KB, wave, lane, i, 0x7fffffff);
+#pragma unroll
+        for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, tc.n * BN, i_k * KB, wave, lane, i, 0x7fffffff);
+    };
     auto issue = [&]() {
-        if (i_new) {
-            const TileCoord tc = tile_coord(tb + i_tile, g.tiles_m, g.tiles_n);
-            kp = i_k + (sk.krot ? (int)(((long long)(tb + i_tile) * sk.krot) % nk) : 0);
-            if (kp >= nk) kp -= nk;
-#pragma unroll
-            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, tc.m * BM, kp * KB, wave, lane, i, 0x7fffffff);
-#pragma unroll
-            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, tc.n * BN, kp * KB, wave, lane, i, 0x7fffffff);
-            i_new = false;
-        }
         float* As = smem + st_in * STAGE;
         float* Bs = As + SA;
         st_in ^= 1;
-        if (g.ktail && kp == nk - 1) {           // K tail (krot == 0 there): clamped k rows; the piece ends with this k-tile, the pointers are rebuilt
+        if (g.ktail && i_k == nk - 1) {          // K tail: clamped k rows (the tile ends with this k-tile: the pointers are rebuilt behind it)
             const TileCoord tc = tile_coord(tb + i_tile, g.tiles_m, g.tiles_n);
 #pragma unroll
-            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, tc.m * BM, kp * KB, wave, lane, i, g.K - 1);
+            for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, tc.m * BM, i_k * KB, wave, lane, i, g.K - 1);
 #pragma unroll
-            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, tc.n * BN, kp * KB, wave, lane, i, g.K - 1);
+            for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, tc.n * BN, i_k * KB, wave, lane, i, g.K - 1);
         }
 #pragma unroll
         for (int i = 0; i < TA::NI; ++i) {
@@ -132,15 +165,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
             pb[i] += sb;
         }
-        if (++kp == nk) {                        // rotated contraction wraps to the first k-tile
-            kp = 0;
-#pragma unroll
-            for (int i = 0; i < TA::NI; ++i) pa[i] -= (int64_t)nk * sa;
-#pragma unroll
-            for (int i = 0; i < TB::NI; ++i) pb[i] -= (int64_t)nk * sb;
-        }
         --i_rem;
-        if (++i_k == nk) { i_k = 0; i_tile += tile_step; i_new = true; }
+        if (++i_k == nk) {
+            i_k = 0; i_tile += tile_step;
+            if (i_rem > 0) setup_ptrs();
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
     };
     zero_acc();
 
-    if (i_rem > 0) issue();
+    if (i_rem > 0) { setup_ptrs(); issue(); }
     bool first = true;
     while (c_rem > 0) {
         wait_vmcnt<0>();                          // my pieces of this k-tile have landed (and the previous piece's stores are acknowledged)
@@ -185,61 +214,78 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
         if (c_k == nk || c_rem == 0) {            // the piece [c_k0, c_k) of tile c_tile is complete
             stamp();                              // main loop of the piece done
             const TileCoord tc = tile_coord(tb + c_tile, g.tiles_m, g.tiles_n);
-            if (c_k0 > 0) {
-                // ---- producer: dump the accumulators in fragment order, then raise the flag -----------------------------------------------
-                float4* dst = reinterpret_cast<float4*>(sk.partials + (size_t)my_slot * SLOT) + tid;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            dst[(size_t)((i * TN + j) * 4 + q) * (NW * 64)] =
-                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                wait_vmcnt<0>();                  // acknowledged by the L2
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(sk.ctl + SK_CTL_FLAG + my_slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (c_k < nk) {
-                    // ---- head: add the partial tiles of the following ranges in ascending k order ------------------------------------------
-                    int kk = c_k, j = r + 1;
-                    while (kk < nk) {
-                        int s, e;
-                        sk_range(sk, j, ntg, s, e);
-                        if (e == s) { ++j; continue; }          // an empty range (fewer iterations than workgroups) produces nothing
-                        const int slot = group * sk.gsize + j;
-                        while (__hip_atomic_load(sk.ctl + SK_CTL_FLAG + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-                            __builtin_amdgcn_s_sleep(2);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        const float4* src = reinterpret_cast<const float4*>(sk.partials + (size_t)slot * SLOT) + tid;
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const float4 v = src[(size_t)((i * TN + jj) * 4 + q) * (NW * 64)];
-                                    acc[i][jj][4 * q] += v.x; acc[i][jj][4 * q + 1] += v.y;
-                                    acc[i][jj][4 * q + 2] += v.z; acc[i][jj][4 * q + 3] += v.w;
-                                }
-                        kk += min(e - s, nk - kk);
-                        ++j;
-                    }
-                    __syncthreads();              // every wave has seen the flags: clear them for the next launch
-                    if (tid == 0)
-                        for (int jj = r + 1; jj < j; ++jj)
-                            __hip_atomic_store(sk.ctl + SK_CTL_FLAG + group * sk.gsize + jj, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if (!SK || (c_k0 == 0 && c_k == nk)) {
                 gemm_epilogue<TM, TN>(g, acc, tc.m * BM + wm0, tc.n * BN + wn0, l31, half, 0);
+            } else if constexpr (SK) {
+                // ---- a piece of a shared tile: dump the accumulators in fragment order (write-through: visible on every XCD once acknowledged) ------
+                // Both the producers (k0 > 0) and the head (k0 == 0) do this: the head then rebuilds the tile from memory, 32x32 sub-tile by
+                // sub-tile, so the 128 accumulator registers are only ever READ here (a path that modifies them in front of the epilogue makes
+                // hipcc spill all of them around every piece end, whole tiles included).
+                const uint32_t voff = (uint32_t)tid * 16u;
+                {
+                    const char* const dst = reinterpret_cast<const char*>(sk.partials + (size_t)my_slot * SLOT);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                store16_sc1(voff, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]},
+                                            dst + (size_t)((i * TN + j) * 4 + q) * (NW * 64 * 16));
+                }
+                wait_vmcnt<0>();                  // every storing wave drains its write-through stores
+                __syncthreads();
+                if (c_k0 > 0) {                   // producer: raise the flag
+                    if (tid == 0) __hip_atomic_store(sk.ctl + SK_CTL_FLAG + my_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {                          // head: wait for ranges r + 1 .. jend - 1 (one wave polls relaxed, one acquire), then add in ascending k order
+                    if (wave == 0) {
+                        for (int j = r + 1; j < jend; ++j)
+                            while (__hip_atomic_load(sk.ctl + SK_CTL_FLAG + group * sk.gsize + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                                __builtin_amdgcn_s_sleep(4);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const char* const base = reinterpret_cast<const char*>(sk.partials + (size_t)(group * sk.gsize) * SLOT);
+#pragma unroll 1
+                    for (int gi = 0; gi < TM * TN; ++gi) {
+                        f32x16 sum[1][1];
+                        {
+                            f32x4 buf[4];         // (a thread reads back exactly the 16-byte pieces it wrote itself)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) load16(buf[q], voff, base + (size_t)r * (SLOT * 4) + (size_t)(gi * 4 + q) * (NW * 64 * 16));
+                            wait16<0>(buf);
+                            typedef float f32x8 __attribute__((ext_vector_type(8)));
+                            const f32x8 lo = __builtin_shufflevector(buf[0], buf[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                            const f32x8 hi = __builtin_shufflevector(buf[2], buf[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                            sum[0][0] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                        }
+#pragma unroll 1
+                        for (int j = r + 1; j < jend; ++j) {
+                            f32x4 buf[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) load16(buf[q], voff, base + (size_t)j * (SLOT * 4) + (size_t)(gi * 4 + q) * (NW * 64 * 16));
+                            wait16<0>(buf);
+                            typedef float f32x8 __attribute__((ext_vector_type(8)));
+                            const f32x8 lo = __builtin_shufflevector(buf[0], buf[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                            const f32x8 hi = __builtin_shufflevector(buf[2], buf[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                            sum[0][0] += __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                        }
+                        gemm_epilogue<1, 1>(g, sum, tc.m * BM + wm0 + 32 * (gi / TN), tc.n * BN + wn0 + 32 * (gi % TN), l31, half, 0);
+                    }
+                    if (tid == 0)
+                        for (int j = r + 1; j < jend; ++j)
+                            __hip_atomic_store(sk.ctl + SK_CTL_FLAG + group * sk.gsize + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             stamp();                              // epilogue / dump issued
             zero_acc();
             c_k0 = 0;
             if (c_k == nk) { c_k = 0; c_tile += tile_step; }
+            if (i_rem > 0) setup_ptrs();          // (the next k-tile of the issue cursor: see setup_ptrs)
         }
     }
-    // ---- leave the control block zeroed: the last workgroup of the group to finish resets ticket and done counters --------------------
-    if (tid == 0) {
+    // ---- stream-K: leave the control block zeroed -- the last workgroup of the group to finish resets ticket and done counters -------------
+    if (SK && tid == 0) {
         const unsigned d = __hip_atomic_fetch_add(sk.ctl + SK_CTL_DONE + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)d == sk.gsize - 1) {
             __hip_atomic_store(sk.ctl + SK_CTL_TICKET + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -284,7 +330,7 @@ SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, boo
         for (int dp = 0; dp <= 1; ++dp) {
             if ((mode == 2 && !dp) || (mode == 3 && dp)) continue;
             const double iters = dp ? (double)cdiv(ntg, gsize) * nk : (double)cdiv((int64_t)ntg * nk, gsize);
-            if (!dp && iters < 4) continue;
+            if (!dp && (iters < 4 || (double)ntg * nk * gsize >= 2147483648.0 || (int64_t)(ntiles / ngroups) * nk < gsize)) continue;
             const double tile_bytes = (double)bm * bn * 4.0;
             // DP: ~2 us of un-overlapped epilogue per tile; SK: one partial dump and, for the heads, (pieces - 1) partial reads at ~150 GB/s
             const double pieces = dp ? 1.0 : std::max(1.0, (double)nk / iters + 1.0);
@@ -305,8 +351,13 @@ int64_t sk_workspace_elems(const SkPlan& p) {
 template <int BM, int BN>
 static void sk_launch_tile(const GemmArgs& g, const SkArgs& sk, int transB, hipStream_t s) {
     const dim3 grid(sk.G), blk(512);
-    if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32>), grid, blk, 0, s, g, sk);
-    else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32>), grid, blk, 0, s, g, sk);
+    if (sk.dp) {
+        if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32, false>), grid, blk, 0, s, g, sk);
+        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32, false>), grid, blk, 0, s, g, sk);
+    } else {
+        if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32, true>), grid, blk, 0, s, g, sk);
+        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32, true>), grid, blk, 0, s, g, sk);
+    }
 }
 
 void sk_launch(GemmArgs& g, const SkPlan& p, int transB, float* partials, unsigned* ctl, hipStream_t s) {
@@ -317,9 +368,10 @@ void sk_launch(GemmArgs& g, const SkPlan& p, int transB, float* partials, unsign
     g.splits = 1;
     SkArgs sk;
     sk.G = p.G; sk.ngroups = p.ngroups; sk.gsize = p.G / p.ngroups;
+    sk.gshift = -1;
+    for (int b = 0; b < 12; ++b) if ((1 << b) == sk.gsize) sk.gshift = b;
     sk.nk = g.Kloop / BK;
     sk.dp = p.dp;
-    sk.krot = g.ktail ? 0 : std::max(0, opt(OPT_GEMM_KROT));
     for (int x = 0; x <= 8; ++x) sk.tile_begin[x] = x <= p.ngroups ? (int)((int64_t)g.ntiles * x / p.ngroups) : g.ntiles;
     sk.partials = partials;
     sk.ctl = ctl;

@@ -181,11 +181,116 @@ __device__ __forceinline__ void epilogue_body(const GemmArgs& g, f32x16 (&acc)[T
     }
 }
 
+// Interior tiles (every row and column of the wave's sub-tile inside the matrix): the same arithmetic with the addressing rebuilt for the
+// register file.  row0 / col0 are wave-uniform, so the address of every store is (scalar base of its row) + ONE per-lane byte offset that is the
+// same for the whole epilogue (4 * half rows down, l31 columns right): `global_store_dword voff, data, s[base]`.  The generic body above keeps a
+// 64-bit pointer per row group alive next to the 128 accumulators; hipcc then spills a handful of them and -- scratch reloads and global stores
+// share the in-order vmcnt counter -- every reload waits for ALL stores issued before it: ~30 store round trips per 256x256 tile (round 5
+// timeline: 29 us for the epilogue of a 256x256 tile against 4 us for a 256x128 one; this was the launch-per-tile kernel's 25 us "fixed cost").
+// ---- memory operations of the interior epilogue, written out: scalar row base + one 32-bit per-lane byte offset -------------------------------
+// (hipcc turns the C++ form of "uniform pointer + per-lane offset" into 64-bit per-lane address arithmetic or, through integer casts, into FLAT
+// accesses; the saddr form needs no address registers at all.)  Loads issued this way are invisible to the compiler's s_waitcnt insertion:
+// epi_wait<N>() is the explicit wait and names the loaded registers so that no use can be scheduled above it.
+// a wave-uniform pointer pinned into scalar registers (callers whose wave index is not provably uniform to the compiler, e.g. tid >> 6)
+template <class T>
+__device__ __forceinline__ T* scalar_ptr(T* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void epi_store(uint32_t voff, float v, const void* sbase) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void epi_load(float& d, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void epi_wait(float (&a)[4], float (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+// Interior tiles (every row and column of the wave's sub-tile inside the matrix): the arithmetic of epilogue_body with the addressing rebuilt for
+// the register file.  row0 / col0 are wave-uniform, so every access is (scalar base of its row) + ONE per-lane byte offset that is the same for
+// the whole epilogue (4 * half rows down, l31 columns right).  The generic body keeps 64-bit per-lane pointers alive next to the 128 accumulators
+// of a 256x256 tile; hipcc spilled a handful of them and -- scratch reloads and global stores share the in-order vmcnt counter -- every reload
+// waited for ALL stores issued before it: ~30 store round trips per tile (round-5 timeline: 29 us for the epilogue of a 256x256 tile against 4 us
+// for a 256x128 one; this was the launch-per-tile kernel's 25 us of "fixed cost").  Epilogues that READ a matrix (beta, x GELU', x ReLU') are
+// software-pipelined: the loads of row group g + 1 are issued before the stores of group g, and the wait counts the operations behind them.
+template <int TM, int TN, int EPI, bool BETA>
+__device__ __forceinline__ void epilogue_interior(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half) {
+    constexpr bool AUX_IN = EPI == YTVLN_EPI_MUL_DGELU || EPI == YTVLN_EPI_MUL_DRELU;
+    constexpr int NL = (AUX_IN ? 4 : 0) + (BETA ? 4 : 0);         // loads per row group
+    constexpr int NST = 4;                                        // stores per row group (8 when GELU also writes its pre-activation: the wait below stays conservative)
+    constexpr int G = TN * TM * 4;
+    const uint32_t vc = (uint32_t)(((int64_t)(4 * half) * g.ldc + l31) * 4);          // per-lane byte offsets (4 rows + 32 columns: < 2^32)
+    const uint32_t vx = (uint32_t)(((int64_t)(4 * half) * g.ldaux + l31) * 4);
+    const char* const cb = scalar_ptr(reinterpret_cast<const char*>(g.C + (int64_t)row0 * g.ldc + col0));
+    const char* const xb = (EPI != YTVLN_EPI_NONE && EPI != YTVLN_EPI_RELU && g.aux) ? scalar_ptr(reinterpret_cast<const char*>(g.aux + (int64_t)row0 * g.ldaux + col0)) : nullptr;
+    const int64_t cs = g.ldc * 4, xs = g.ldaux * 4;               // row strides in bytes
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = g.bias ? g.bias[col0 + 32 * j + l31] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]));          // the bias loads are the compiler's: its waits land here, before the hand-counted part
+    float ax[2][4] = {}, old[2][4] = {};
+    auto row_c = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; return cb + (int64_t)(32 * i + 8 * q) * cs + 128 * j; };
+    auto row_x = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; return xb + (int64_t)(32 * i + 8 * q) * xs + 128 * j; };
+    auto loads = [&](auto gc) {
+        constexpr int gi = decltype(gc)::value;
+        if constexpr (AUX_IN) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) epi_load(ax[gi & 1][u], vx, row_x(gi) + u * xs);
+        }
+        if constexpr (BETA) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) epi_load(old[gi & 1][u], vc, row_c(gi) + u * cs);
+        }
+    };
+    if constexpr (NL > 0) loads(std::integral_constant<int, 0>{});
+    static_for<G>([&](auto gc) {
+        constexpr int gi = decltype(gc)::value;
+        constexpr int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4;
+        if constexpr (NL > 0) {
+            if constexpr (gi + 1 < G) loads(std::integral_constant<int, gi + 1>{});
+            epi_wait<(gi > 0 ? NST : 0) + (gi + 1 < G ? NL : 0)>(ax[gi & 1], old[gi & 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = acc[i][j][4 * q + u] + bv[j];
+            if (EPI == YTVLN_EPI_GELU) {
+                if (xb) epi_store(vx, v, row_x(gi) + u * xs);
+                v = gelu_erf(v);
+            } else if (EPI == YTVLN_EPI_RELU) {
+                v = fmaxf(v, 0.f);
+            } else if (EPI == YTVLN_EPI_MUL_DGELU) {
+                v *= dgelu_erf(ax[gi & 1][u]);
+            } else if (EPI == YTVLN_EPI_MUL_DRELU) {
+                v = ax[gi & 1][u] > 0.f ? v : 0.f;
+            }
+            if (BETA) v += g.beta * old[gi & 1][u];
+            epi_store(vc, v, row_c(gi) + u * cs);
+        }
+    });
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half, int split) {
     const bool interior = row0 + 32 * TM <= g.M && col0 + 32 * TN <= g.N;
     if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
         float* w = g.ws + (int64_t)split * g.M * g.N;
+        if (interior) {          // scalar row bases + one per-lane offset (see epilogue_interior)
+            const uint32_t vw = (uint32_t)(((int64_t)(4 * half) * g.N + l31) * 4);
+            const char* const wb = scalar_ptr(reinterpret_cast<const char*>(w + (int64_t)row0 * g.N + col0));
+            const int64_t wsb = (int64_t)g.N * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        epi_store(vw, acc[i][j][r], wb + (int64_t)(32 * i + (r & 3) + 8 * (r >> 2)) * wsb + 128 * j);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = col0 + 32 * j + l31;
@@ -205,7 +310,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
     }
 #define YT_EPI(E)                                                                        \
     case E:                                                                              \
-        if (interior) epilogue_body<TM, TN, E, true>(g, acc, row0, col0, l31, half);     \
+        if (interior) { if (g.beta != 0.f) epilogue_interior<TM, TN, E, true>(g, acc, row0, col0, l31, half); else epilogue_interior<TM, TN, E, false>(g, acc, row0, col0, l31, half); } \
         else epilogue_body<TM, TN, E, false>(g, acc, row0, col0, l31, half);             \
         break;
     switch (g.epilogue) {
@@ -214,7 +319,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
         YT_EPI(YTVLN_EPI_MUL_DGELU)
         YT_EPI(YTVLN_EPI_MUL_DRELU)
         default:
-            if (interior) epilogue_body<TM, TN, YTVLN_EPI_NONE, true>(g, acc, row0, col0, l31, half);
+            if (interior) { if (g.beta != 0.f) epilogue_interior<TM, TN, YTVLN_EPI_NONE, true>(g, acc, row0, col0, l31, half); else epilogue_interior<TM, TN, YTVLN_EPI_NONE, false>(g, acc, row0, col0, l31, half); }
             else epilogue_body<TM, TN, YTVLN_EPI_NONE, false>(g, acc, row0, col0, l31, half);
             break;
     }

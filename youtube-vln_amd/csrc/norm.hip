@@ -44,6 +44,20 @@ __device__ __forceinline__ float4 f4scale_keep(float4 v, u32x4 b, uint32_t thr, 
                        b.w >= thr ? v.w * ik : 0.f);
 }
 
+// Dropout draws of a row kernel.  fp32 rows: one Philox call per 4 elements, 32-bit draws (index row * H/4 + c4).  bf16 rows with
+// H % 8 == 0: one call per 8 elements, 16-bit draws (index row * H/8 + c8) -- the scheme of the 16-bytes-per-lane kernels
+// (ln_*_bf16x8_kernel).  The scheme is a function of the row type and H ALONE, never of pointer alignment or of which kernel form a
+// launch happens to take, so a forward and its backward always regenerate the same mask (the embedding forwards run the 4-wide kernels,
+// their backward the 8-wide one).
+__device__ __forceinline__ uint32_t drop_threshold16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ float4 drop4(float4 v, const DropKey& key, uint64_t row, int H4, int c4, bool x8, uint32_t thr, float ik) {
+    if (!x8) return f4scale_keep(v, drop_bits(key, row * H4 + c4), thr, ik);
+    const u32x4 b = drop_bits(key, row * (uint64_t)(H4 >> 1) + (c4 >> 1));
+    const uint32_t w0 = (c4 & 1) ? b.z : b.x, w1 = (c4 & 1) ? b.w : b.y;
+    return make_float4((w0 & 0xffffu) >= thr ? v.x * ik : 0.f, (w0 >> 16) >= thr ? v.y * ik : 0.f,
+                       (w1 & 0xffffu) >= thr ? v.z * ik : 0.f, (w1 >> 16) >= thr ? v.w * ik : 0.f);
+}
+
 template <int NV, int MODE, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
     const XT* const xin = reinterpret_cast<const XT*>(a.x);
@@ -54,13 +68,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
     const int H4 = a.H >> 2;
     const float invH = 1.0f / (float)a.H;
     const bool pre = a.p_pre > 0.f, post = a.p_post > 0.f;
+    const bool x8 = std::is_same<YT, bf16_t>::value && (a.H % 8 == 0);       // draw scheme: see drop4
     DropKey key = {0, 0, 0, 0};
     uint32_t thr_pre = 0, thr_post = 0;
     float ik_pre = 1.f, ik_post = 1.f;
     if (pre || post) {
         key = make_drop_key(a.rng, a.site);
-        thr_pre = drop_threshold(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
-        thr_post = drop_threshold(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
+        thr_pre = x8 ? drop_threshold16(a.p_pre) : drop_threshold(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
+        thr_post = x8 ? drop_threshold16(a.p_post) : drop_threshold(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
         float4 s[NV];
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
             if (c4 < H4) {
                 if (MODE == LN_PLAIN) {
                     v = ld4(xin + row * a.H, c4);
-                    if (pre) v = f4scale_keep(v, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre);
+                    if (pre) v = drop4(v, key, (uint64_t)row, H4, c4, x8, thr_pre, ik_pre);
                     if (rin) v = f4add(v, ld4(rin + row * a.H, c4));
                 } else if (MODE == LN_TEXT) {
                     v = f4add(f4add(reinterpret_cast<const float4*>(wrow)[c4], reinterpret_cast<const float4*>(prow)[c4]),
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
                 const float4 g = reinterpret_cast<const float4*>(a.gamma)[c4], b = reinterpret_cast<const float4*>(a.beta)[c4];
                 float4 o = make_float4(g.x * ((s[j].x - mu) / sd) + b.x, g.y * ((s[j].y - mu) / sd) + b.y,
                                        g.z * ((s[j].z - mu) / sd) + b.z, g.w * ((s[j].w - mu) / sd) + b.w);
-                if (post) o = f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_post, ik_post);
+                if (post) o = drop4(o, key, (uint64_t)row, H4, c4, x8, thr_post, ik_post);
                 st4(yout + row * a.H, c4, o);
             }
         }
@@ -161,13 +176,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     const int H4 = a.H >> 2;
     const float invH = 1.0f / (float)a.H;
     const bool pre = a.p_pre > 0.f, post = a.p_post > 0.f;
+    const bool x8 = std::is_same<XT, bf16_t>::value && (a.H % 8 == 0);       // draw scheme: see drop4
     DropKey key = {0, 0, 0, 0};
     uint32_t thr_pre = 0, thr_post = 0;
     float ik_pre = 1.f, ik_post = 1.f;
     if (pre || post) {
         key = make_drop_key(a.rng, a.site);
-        thr_pre = drop_threshold(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
-        thr_post = drop_threshold(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
+        thr_pre = x8 ? drop_threshold16(a.p_pre) : drop_threshold(a.p_pre); ik_pre = 1.0f / (1.0f - a.p_pre);
+        thr_post = x8 ? drop_threshold16(a.p_post) : drop_threshold(a.p_post); ik_post = 1.0f / (1.0f - a.p_post);
     }
     float4 dg[NV], db[NV], gm[NV];
 #pragma unroll
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             g[j] = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = g[j];
             if (c4 < H4) {
                 float4 d = ld4(dyin + row * a.H, c4);
-                if (post) d = f4scale_keep(d, drop_bits(key, (uint64_t)row * H4 + c4), thr_post, ik_post);
+                if (post) d = drop4(d, key, (uint64_t)row, H4, c4, x8, thr_post, ik_post);
                 const float4 sv = ld4(sin + row * a.H, c4);
                 xh[j] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
                 dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
                                        rs * (g[j].z - c1 - xh[j].z * c2), rs * (g[j].w - c1 - xh[j].w * c2));
                 if (dsout) st4(dsout + row * a.H, c4, o);
                 if (a.ds_f32) st4(a.ds_f32 + row * a.H, c4, o);
-                if (pre && dxout) st4(dxout + row * a.H, c4, f4scale_keep(o, drop_bits(key, (uint64_t)row * H4 + c4), thr_pre, ik_pre));
+                if (pre && dxout) st4(dxout + row * a.H, c4, drop4(o, key, (uint64_t)row, H4, c4, x8, thr_pre, ik_pre));
             }
         }
     }
@@ -252,7 +268,6 @@ __device__ __forceinline__ f8 ldg8(const float* p, int c8) {
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
 }
-__device__ __forceinline__ uint32_t drop_threshold16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 __device__ __forceinline__ void keep8(f8& r, const u32x4 b, uint32_t thr16, float ik) {          // element e keeps iff its 16 random bits >= thr16
     const uint32_t w[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll

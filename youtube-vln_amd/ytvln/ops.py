@@ -791,7 +791,11 @@ def _bf16_weight(weight: Tensor) -> Tensor:
                 pb = opt.bf16_arena(targets)
                 if pb is not None:
                     return pb[first.off:off].view(weight.shape)
-        # not (all) in the arena: per-parameter cache keyed by (storage pointer, version)
+        # not (all) adjacent in one arena.  Arena members are updated by the fused AdamW kernel through raw pointers, which does not bump
+        # their version counters: a cache keyed on versions would go stale after every optimizer step, so they are cast on the spot.
+        if any(_slot_of(t) is not None for t in targets):
+            return cast_bf16(weight.detach())
+        # per-parameter cache keyed by (storage pointer, version)
         key = tuple((t.data_ptr(), t._version) for t in targets)
         holder = targets[0]
         cached = getattr(holder, "_ytvln_bf16_cache", None)
@@ -1395,6 +1399,12 @@ def _attn_bwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, dout, lse,
 
 def attn_probs(q, q_off, ldq, k, k_off, ldk, mask, lse, N, heads, Tq, Tk, d, scale) -> Tensor:
     probs = torch.empty((N, heads, Tq, Tk), dtype=torch.float32, device=lse.device)
+    if q.dtype == torch.bfloat16 or k.dtype == torch.bfloat16:
+        # bf16-resident path (output_all_attention_masks is a rare diagnostic there): the probability kernel reads fp32 rows, so the
+        # bf16 projections are widened first -- offsets and leading dimensions are in elements and carry over unchanged
+        q, k = q.float(), k.float()
+    elif q.dtype != torch.float32 or k.dtype != torch.float32:
+        raise RuntimeError(f"attn_probs: q / k must be float32 or bfloat16, got {q.dtype} / {k.dtype}")
     call("ytvln_attn_probs_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(mask), _ptr(lse), _ptr(probs), N, heads, Tq, Tk, d,
          float(scale), _stream())
     return probs
