@@ -1056,6 +1056,21 @@ def test_g13_in_batch_pairs_fast_mode_and_predict_feature(dev, lib):
         assert abs(float(pd[n].grad.double().norm()) - ref) <= 2e-4 * ref + 1e-5, n
 
 
+def test_g17_fixed_layers(dev, lib):
+    """`fixed_t_layer` / `fixed_v_layer` (vilbert.py:742-764): the first layers of each stream run under no_grad.  Against the reference's
+    own run (oracle/gen_golden_fixed.py) on a deepened tiny config (4 text / 3 image layers, co-attention after (t 2, v 1) and (t 3, v 2))
+    with fixed_t_layer = 2, fixed_v_layer = 1: outputs, the loss, the exact SET of parameters that receive a gradient (the frozen layers
+    and the embeddings below them get None) and every gradient norm; and the same model with the switches off."""
+    from ytvln import synth
+    g = gold("g17_fixed_layers.npz")
+    deep = dict(num_hidden_layers=4, v_num_hidden_layers=3, t_biattention_id=[2, 3], v_biattention_id=[1, 2])
+    b = synth.to_torch(synth.make_batch(bs=3, K=1, T=12, frames=2, boxes=5, seed=61), dev)
+    inputs = (b[6][:, 0], b[1][:, 0], b[2][:, 0], b[10][:, 0], b[7][:, 0], b[3][:, 0])
+    _check_bert(_bert_model(dev, 31, fixed_t_layer=2, fixed_v_layer=1, **deep), inputs, g, "fixed")
+    _check_bert(_bert_model(dev, 31, **deep), inputs, g, "free")
+    assert len(g["fixed/grad_names"]) < len(g["free/grad_names"])
+
+
 TRAINMODE_RECIPE = dict(bs=2, K=3, T=16, frames=2, boxes=4, seed=31, ignore_rank_frac=0.0)
 
 

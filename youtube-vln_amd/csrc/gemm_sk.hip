@@ -45,11 +45,11 @@ __device__ __forceinline__ void sk_range(const SkArgs& sk, int r, int ntg, int& 
 // 16-byte write-through store (sc1: visible to every XCD once acknowledged, no release fence needed): scalar base + per-lane byte offset
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_sc1(uint32_t voff, f32x4 v, const void* sbase) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");      // (s_nop 4: see epi_store)
 }
 
 __device__ __forceinline__ void load16(f32x4& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait16(f32x4 (&b)[4]) {

@@ -190,7 +190,10 @@ __device__ __forceinline__ void epilogue_body(const GemmArgs& g, f32x16 (&acc)[T
 // ---- memory operations of the interior epilogue, written out: scalar row base + one 32-bit per-lane byte offset -------------------------------
 // (hipcc turns the C++ form of "uniform pointer + per-lane offset" into 64-bit per-lane address arithmetic or, through integer casts, into FLAT
 // accesses; the saddr form needs no address registers at all.)  Loads issued this way are invisible to the compiler's s_waitcnt insertion:
-// epi_wait<N>() is the explicit wait and names the loaded registers so that no use can be scheduled above it.
+// epi_wait<N>() is the explicit wait and names the loaded registers so that no use can be scheduled above it.  The leading `s_nop 4`: a scalar
+// base that the compiler has just produced with a VALU instruction (v_readfirstlane, or v_readlane when it reloads a spilled SGPR) needs five
+// wait states before a memory instruction may read it, and the hazard recogniser does not look inside inline asm (round 5: wild addresses,
+// "memory aperture violation", exactly in the epilogues with enough scalar pressure to spill).
 // a wave-uniform pointer pinned into scalar registers (callers whose wave index is not provably uniform to the compiler, e.g. tid >> 6)
 template <class T>
 __device__ __forceinline__ T* scalar_ptr(T* p) {
@@ -199,10 +202,10 @@ __device__ __forceinline__ T* scalar_ptr(T* p) {
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ void epi_store(uint32_t voff, float v, const void* sbase) {
-    asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void epi_load(float& d, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void epi_wait(float (&a)[4], float (&b)[4]) {
