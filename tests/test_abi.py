@@ -67,7 +67,7 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     with pytest.raises(RuntimeError, match="ytvln_ln_fwd_f32 failed"):
         _lib.call("ytvln_ln_fwd_f32", 16, None, 16, 16, 16, None, None, None, 4, 30, 1e-12, 0.0, 0.0, None, 0, None)   # H % 4 != 0
     assert lib.ytvln_gemm_workspace_elems(1024, 1024, 16128, 0) > 0
-    assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) == 256 * 256 * 256      # one partial tile per workgroup of a stream-K launch
+    assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) == 2 * 256 * 256 * 256      # two banks of one partial tile per workgroup of a stream-K launch
     assert lib.ytvln_gemm_workspace_elems(100, 64, 64, 0) == 0
     assert lib.ytvln_ln_bwd_blocks(16128) == 1008
 

@@ -359,3 +359,139 @@ def test_attention_full_grids_every_block_right_and_reproducible(dev, lib, preci
     for i in range(1, 4):
         for a, b, what in zip(runs[i], runs[0], ("out", "lse", "dqkv")):
             assert torch.equal(a, b), (i, what, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("H", [768, 1024, 36])
+def test_embedding_dropout_masks_match_between_forward_and_backward_bf16(dev, lib, H):
+    """on the bf16-resident path the embedding forwards (4-wide row kernels) and their LayerNorm backward (the 16-bytes-
+    per-lane kernel whenever H % 8 == 0) must regenerate the SAME post-LayerNorm dropout mask.  The draw scheme is now a function of the row
+    type and H alone (csrc/norm.hip drop4).  Check: with p > 0 the gradient that reaches the LayerNorm is zero exactly where the forward
+    output is zero, and equals dy / (1 - p) elsewhere -- read off beta's gradient with one-hot dy, and off the full backward against an fp64
+    LayerNorm backward fed with the mask taken from the forward output."""
+    from ytvln import ops
+    ops.set_matmul_precision("bf16")
+    try:
+        p, N, T, V = 0.25, 6, 20, 50
+        drop = ops.DropoutState(dev)
+        g = torch.Generator().manual_seed(H)
+        ids = torch.randint(1, V, (N, T), generator=g).to(dev)
+        word = torch.randn(V, H, generator=g).to(dev).requires_grad_(True)
+        pos = torch.randn(T + 3, H, generator=g).to(dev).requires_grad_(True)
+        typ = torch.randn(2, H, generator=g).to(dev).requires_grad_(True)
+        gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
+        beta = (0.5 + 0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)      # beta ~ 0.5: a kept output is never exactly 0
+        y = ops.text_embed(ids, None, word, pos, typ, gamma, beta, 1e-12, p, drop)
+        assert y.dtype == BF
+        keep = (y.float() != 0)
+        rate = 1.0 - float(keep.float().mean())
+        assert abs(rate - p) < 0.03, rate
+        dy = torch.randn(N, T, H, generator=g).to(dev).to(BF)
+        y.backward(dy)
+        # d beta = sum over rows of (dy * keep / (1 - p)): exact statement of "the backward used the forward's mask"
+        ref_db = (dy.double() * keep.double() / (1 - p)).view(-1, H).sum(0)
+        assert rel_l2(beta.grad, ref_db) < 2e-3, rel_l2(beta.grad, ref_db)
+        wrong_db = (dy.double() / 1.0).view(-1, H).sum(0) * (1 - rate) / (1 - p)          # what an unrelated mask would give in expectation
+        assert rel_l2(beta.grad, wrong_db) > 0.1
+        # image side
+        R = 12
+        img = torch.randn(N, R, H, generator=g).to(dev).to(BF).requires_grad_(True)
+        loc = torch.rand(N, R, 12, generator=g).to(dev)
+        loc[..., 11] = torch.randint(0, 4, (N, R), generator=g).to(dev).float()
+        W5, b5 = torch.randn(H, 5, generator=g).to(dev).requires_grad_(True), torch.randn(H, generator=g).to(dev).requires_grad_(True)
+        W4, b4 = torch.randn(H, 4, generator=g).to(dev).requires_grad_(True), torch.randn(H, generator=g).to(dev).requires_grad_(True)
+        W2, b2 = torch.randn(H, 2, generator=g).to(dev).requires_grad_(True), torch.randn(H, generator=g).to(dev).requires_grad_(True)
+        E = torch.randn(4, H, generator=g).to(dev).requires_grad_(True)
+        beta2 = (0.5 + 0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
+        yi = ops.image_embed(img, loc, W5, b5, W4, b4, W2, b2, E, gamma.detach().requires_grad_(True), beta2, 1e-12, p, drop)
+        keep_i = (yi.float() != 0)
+        dyi = torch.randn(N, R, H, generator=g).to(dev).to(BF)
+        yi.backward(dyi)
+        ref_db2 = (dyi.double() * keep_i.double() / (1 - p)).view(-1, H).sum(0)
+        assert rel_l2(beta2.grad, ref_db2) < 2e-3, rel_l2(beta2.grad, ref_db2)
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
+def _tile_max_err(C, ref, t=256):
+    M, N = C.shape
+    pm, pn = (-M) % t, (-N) % t
+    d = torch.nn.functional.pad((C.double() - ref).abs(), (0, pn, 0, pm))
+    return d.view((M + pm) // t, t, (N + pn) // t, t).amax(dim=(1, 3))
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(129024, 1024, 1024, 0, 1), (17920, 3072, 768, 0, 1), (17920, 768, 3072, 0, 0), (1024, 1024, 129024, 1, 0),
+                                         (129024, 1024, 1024, 0, 0)])
+def test_gemm_bf16_full_grids_every_tile_right_and_reproducible(dev, lib, M, N, K, ta, tb):
+    """the bf16 GEMM's LDS-DMA ring at the grid sizes of BASELINE configs[4] (224 pairs x 576 regions = 129024 image rows,
+    17920 text rows), judged PER 256x256 output tile against fp64 on the same bf16 inputs, bit-identical over repeated launches, alone and
+    beside a busy second stream (tools/bf16_repro.py promoted to a test: a write-after-read race on a ring slot shows up as a few wrong
+    tiles, different ones every run, invisible to a whole-matrix relative L2)."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn((K, M) if ta else (M, K), generator=g) * 0.5).to(dev).to(BF)
+    B = (torch.randn((N, K) if tb else (K, N), generator=g) * 0.5).to(dev).to(BF)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    scale = float(ref.abs().max())
+    side = torch.cuda.Stream()
+    X, W = torch.randn(4096, 1024, device=dev), torch.randn(1024, 1024, device=dev)
+    first = None
+    for i in range(12):
+        C = torch.full((M, N), 7.0, device=dev, dtype=torch.float32)
+        torch.cuda.synchronize()
+        if i >= 6:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    ops.linear(X, W, None)
+        _gemm(ops, A, ta, B, tb, C, M, N, K)
+        torch.cuda.synchronize()
+        if i in (0, 6):
+            err = _tile_max_err(C, ref)
+            assert float(err.max()) < 3e-6 * scale * max(1.0, math.sqrt(K / 1024)), (i, float(err.max()), (err > 1e-5 * scale).nonzero()[:8].tolist())
+        if first is None:
+            first = C.clone()
+        else:
+            assert torch.equal(C, first), (i, float((C - first).abs().max()))
+
+
+@pytest.mark.parametrize("rows,H,bf", [(16128, 1024, False), (4480, 768, False), (129024, 1024, True), (17920, 768, True)])
+def test_layernorm_full_grids_every_row_right_and_reproducible(dev, lib, rows, H, bf):
+    """VERDICT r4 item 6 for the row kernels: residual + LayerNorm forward and backward at the cfg-2 (fp32) and cfg-5 (bf16) row counts, every
+    ROW against fp64 (row-wise max error, not a whole-tensor norm), bit-identical over repeated launches beside a busy second stream."""
+    from ytvln import ops
+    g = torch.Generator().manual_seed(rows + H)
+    cast = (lambda t: t.to(BF)) if bf else (lambda t: t)
+    x, res = cast(torch.randn(rows, H, generator=g).to(dev)), cast(torch.randn(rows, H, generator=g).to(dev))
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
+    beta = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
+    dy = cast(torch.randn(rows, H, generator=g).to(dev))
+    s = x.double() + res.double()
+    mu, var = s.mean(-1, keepdim=True), s.var(-1, unbiased=False, keepdim=True)
+    xh = (s - mu) / torch.sqrt(var + 1e-12)
+    yr = gamma.detach().double() * xh + beta.detach().double()
+    gg = dy.double() * gamma.detach().double()
+    dsr = (gg - gg.mean(-1, keepdim=True) - xh * (gg * xh).mean(-1, keepdim=True)) / torch.sqrt(var + 1e-12)
+    side = torch.cuda.Stream()
+    X, W = torch.randn(4096, 1024, device=dev), torch.randn(1024, 1024, device=dev)
+    first = None
+    for i in range(8):
+        xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        gamma.grad = beta.grad = None
+        torch.cuda.synchronize()
+        if i >= 4:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    ops.linear(X, W, None)
+        y = ops.add_layer_norm(xr, rr, gamma, beta, 1e-12)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        if i in (0, 4):
+            ey = (y.detach().double() - yr).abs().amax(-1)
+            ed = (xr.grad.double() - dsr).abs().amax(-1)
+            by, bd = (4e-2, 8e-2) if bf else (2e-5, 1e-4)          # bf16: one rounding of values up to ~5 / gradients up to ~10
+            assert float(ey.max()) < by and float(ed.max()) < bd, (i, float(ey.max()), float(ed.max()), (ey > by).nonzero()[:4].tolist())
+        cur = (y.detach().clone(), xr.grad.clone(), gamma.grad.clone(), beta.grad.clone())
+        if first is None:
+            first = cur
+        else:
+            for a, b, what in zip(cur, first, ("y", "dx", "dgamma", "dbeta")):
+                assert torch.equal(a, b), (i, what)

@@ -37,16 +37,40 @@ def timed(fn, iters=ITERS):
 
 
 probe = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
+PASSES = int(os.environ.get("PASSES", "3"))
+hot_a, hot_b = torch.randn(8192, 8192, device=dev), torch.randn(8192, 8192, device=dev)
+
+
+def heat(ms=400):
+    """Clocks: a timing taken right after an idle gap (allocation, host work) reads up to 15 % slow -- every pass starts behind ~0.4 s of GEMM."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while True:
+        for _ in range(10): torch.mm(hot_a, hot_b)
+        e1.record(); torch.cuda.synchronize()
+        if e0.elapsed_time(e1) > ms: return
+
+
 for (M, N, K, tb) in shapes:
     A = torch.randn(M, K, device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     C = torch.empty(M, N, device=dev)
     go = lambda: ops._gemm(A, K, 0, B, B.stride(0), tb, C, N, M, N, K)
+    lib_go = (lambda: torch.mm(A, B.t(), out=C)) if tb else (lambda: torch.mm(A, B, out=C))
+    best = {}
+    for ps in range(PASSES):          # interleaved passes, the order reversed every other pass: min over passes per configuration
+        heat()
+        order = CONFIGS + [("hipblaslt", None)]
+        for name, o in (order if ps % 2 == 0 else order[::-1]):
+            if o is None:
+                us = timed(lib_go)
+            else:
+                setopts(o)
+                us = timed(go)
+            best[name] = min(best.get(name, 1e30), us)
     line = f"{M:6d} {N:6d} {K:5d} tB{tb} "
-    for name, o in CONFIGS:
-        setopts(o)
-        us = timed(go)
-        line += f" {name} {us:7.1f}us {2.0 * M * N * K / us / 1e6:6.1f}TF |"
+    for name, _ in CONFIGS + [("hipblaslt", None)]:
+        line += f" {name} {best[name]:7.1f}us {2.0 * M * N * K / best[name] / 1e6:6.1f}TF |"
     print(line, flush=True)
     if os.environ.get("PROBE"):
         for name, o in CONFIGS:

@@ -372,8 +372,11 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     // us per 32-deep k-tile at the CU-exclusive rate: native fp32 MFMA | three-bf16-term form (fitted on 16128x1024x1024: the split's
     // VALU work is shared best by the wide wave tiles -- 128x128 is VALU-bound, 256x256 matrix-bound)
     // (64x64 and 256x128 exist only for the native instruction: the three-term planner sees their native cost)
-    static const double tk_f32[5] = {2.14, 1.14, 0.55, 4.16, 8.0}, tk_x3[5] = {1.61, 0.82, 0.55, 4.16, 4.94};
-    static const double tfix[5] = {5.0, 3.0, 3.0, 12.0, 25.0};
+    // Round 5: refitted after the interior epilogue stopped spilling (gemm_tiles.h epilogue_interior): the 256x256 tile's fixed cost fell from
+    // 25 to ~10 us (ramp + first operands ~4, epilogue 4.5, drain) and its k-tile measures 7.5 us in whole-chip launches (16128x{1024,2048,3072}x1024:
+    // 251.8 / 497.8 / 744.3 us = 1 / 2 / 3 rounds of ~249); 128x128: 2.06 us per k-tile, ~1 us fixed (266 / 784 / 1612 us on 4 / 12 / 33 rounds).
+    static const double tk_f32[5] = {2.06, 1.14, 0.55, 4.4, 7.5}, tk_x3[5] = {1.61, 0.82, 0.55, 4.16, 4.94};
+    static const double tfix[5] = {1.0, 3.0, 3.0, 6.0, 10.0};
     // native instruction, M-contiguous A (the weight-gradient layout: both operands k-major, fragments gathered by ds_read_b32): fitted in
     // round 2 on the cfg-2 weight-gradient shapes (tools/r2_gpu37.sh) -- the 128x128 workgroups run at 2.3 us per k-tile there (half the
     // flops per operand byte: ~3.7 TB/s of LDS-DMA at 120 TFLOP/s, the same delivery ceiling the fp32x3 256x256 kernel meets), the 256x256 at 7.3
@@ -387,7 +390,7 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     const double need = tile == 1 ? 2.0 : tile == 2 ? 3.0 : 1.0, per_cu = std::max(1.0, blocks / 256.0);
     const double occ = per_cu < need ? need / per_cu : 1.0;
     // fused activations read / write a second matrix in the epilogue: dearer for the 256-row tiles (64-128 KB per workgroup, no overlap)
-    double tf = tfix[tile] + ((tile >= 3 && epilogue != YTVLN_EPI_NONE) ? 10.0 : 0.0);
+    double tf = tfix[tile] + ((tile >= 3 && epilogue != YTVLN_EPI_NONE) ? 2.0 : 0.0);
     if (x3 && tile == 4 && splits > 1) tf = 10.0;        // raw partial tiles: no fused epilogue to expose
     double t = waves * (tf + (double)(kchunk / BK) * tk[tile] * occ);
     // us: reduce launch + workspace bytes at ~3 TB/s (fitted on the native plans; the three-term plans were fitted with 5 TB/s: their
@@ -498,7 +501,7 @@ extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue)
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
     // the stream-K form of the persistent kernel (K-contiguous A): one partial tile per workgroup
     // (sized for either tile and independent of the run-time options, so a caller may cache the figure)
-    if (M >= 256 && N >= 128) need = std::max<int64_t>(need, (int64_t)sk_num_cus() * 256 * (N >= 256 ? 256 : 128));
+    if (M >= 256 && N >= 128) need = std::max<int64_t>(need, (int64_t)2 * sk_num_cus() * 256 * (N >= 256 ? 256 : 128));
     return need;
 }
 

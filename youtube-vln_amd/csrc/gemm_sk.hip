@@ -27,7 +27,8 @@ struct SkArgs {
     int nk;                     // k-tiles per output tile
     int dp;                     // 1: whole tiles only (tile r, r + gsize, ... of the group), 0: stream-K ranges
     int tile_begin[9];          // group x owns tiles [tile_begin[x], tile_begin[x + 1]) of the grouped tile order
-    float* partials;            // [G][slot]: slot = one accumulator dump in fragment order (NW * 64 lanes x 16 * TM * TN floats)
+    float* partials;            // [2 G][slot]: slot = one accumulator dump in fragment order (NW * 64 lanes x 16 * TM * TN floats); first bank: partial tiles of
+                                // the producers, second bank: the heads' own accumulators
     unsigned* ctl;              // zero-initialised: [0, 8) tickets, [8, 16) done counters, [16, 16 + G) partial-ready flags
     unsigned long long* probe;  // optional timeline: 16 s_memrealtime stamps (100 MHz) per workgroup
 };
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
                 // hipcc spill all of them around every piece end, whole tiles included).
                 const uint32_t voff = (uint32_t)tid * 16u;
                 {
-                    const char* const dst = reinterpret_cast<const char*>(sk.partials + (size_t)my_slot * SLOT);
+                    // (a head parks its own accumulators in the second bank of slots: its first piece may have published slot my_slot already)
+                    const char* const dst = reinterpret_cast<const char*>(sk.partials + (size_t)(my_slot + (c_k0 > 0 ? 0 : sk.G)) * SLOT);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, c
                         {
                             f32x4 buf[4];         // (a thread reads back exactly the 16-byte pieces it wrote itself)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) load16(buf[q], voff, base + (size_t)r * (SLOT * 4) + (size_t)(gi * 4 + q) * (NW * 64 * 16));
+                            for (int q = 0; q < 4; ++q) load16(buf[q], voff, base + (size_t)(sk.G + r) * (SLOT * 4) + (size_t)(gi * 4 + q) * (NW * 64 * 16));
                             wait16<0>(buf);
                             typedef float f32x8 __attribute__((ext_vector_type(8)));
                             const f32x8 lo = __builtin_shufflevector(buf[0], buf[1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -345,7 +347,7 @@ SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, boo
 int64_t sk_workspace_elems(const SkPlan& p) {
     if (!p.use || p.dp) return 0;
     const int bn = p.tile == 4 ? 256 : 128;
-    return (int64_t)p.G * 256 * bn;
+    return (int64_t)2 * p.G * 256 * bn;
 }
 
 template <int BM, int BN>

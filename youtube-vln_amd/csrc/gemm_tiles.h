@@ -236,17 +236,21 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
     for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]));          // the bias loads are the compiler's: its waits land here, before the hand-counted part
     float ax[2][4] = {}, old[2][4] = {};
-    auto row_c = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; return cb + (int64_t)(32 * i + 8 * q) * cs + 128 * j; };
-    auto row_x = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; return xb + (int64_t)(32 * i + 8 * q) * xs + 128 * j; };
+    // (each group's row base goes through an opaque asm: left alone, hipcc works out all 128 row bases of the epilogue at once, needs ~250 scalar
+    //  registers for them and spills scalars into VGPR lanes -- inside a persistent kernel even in the main loop)
+    auto row_c = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; const char* p = cb + (int64_t)(32 * i + 8 * q) * cs + 128 * j; asm volatile("" : "+s"(p)); return p; };
+    auto row_x = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; const char* p = xb + (int64_t)(32 * i + 8 * q) * xs + 128 * j; asm volatile("" : "+s"(p)); return p; };
     auto loads = [&](auto gc) {
         constexpr int gi = decltype(gc)::value;
         if constexpr (AUX_IN) {
+            const char* const px = row_x(gi);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) epi_load(ax[gi & 1][u], vx, row_x(gi) + u * xs);
+            for (int u = 0; u < 4; ++u) epi_load(ax[gi & 1][u], vx, px + u * xs);
         }
         if constexpr (BETA) {
+            const char* const pc = row_c(gi);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) epi_load(old[gi & 1][u], vc, row_c(gi) + u * cs);
+            for (int u = 0; u < 4; ++u) epi_load(old[gi & 1][u], vc, pc + u * cs);
         }
     };
     if constexpr (NL > 0) loads(std::integral_constant<int, 0>{});
@@ -257,11 +261,13 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& g, f32x16 (&ac
             if constexpr (gi + 1 < G) loads(std::integral_constant<int, gi + 1>{});
             epi_wait<(gi > 0 ? NST : 0) + (gi + 1 < G ? NL : 0)>(ax[gi & 1], old[gi & 1]);
         }
+        const char* const pc = row_c(gi);
+        const char* const px = (EPI == YTVLN_EPI_GELU && xb) ? row_x(gi) : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float v = acc[i][j][4 * q + u] + bv[j];
             if (EPI == YTVLN_EPI_GELU) {
-                if (xb) epi_store(vx, v, row_x(gi) + u * xs);
+                if (px) epi_store(vx, v, px + u * xs);
                 v = gelu_erf(v);
             } else if (EPI == YTVLN_EPI_RELU) {
                 v = fmaxf(v, 0.f);
@@ -271,7 +277,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& g, f32x16 (&ac
                 v = ax[gi & 1][u] > 0.f ? v : 0.f;
             }
             if (BETA) v += g.beta * old[gi & 1][u];
-            epi_store(vc, v, row_c(gi) + u * cs);
+            epi_store(vc, v, pc + u * cs);
         }
     });
 }
