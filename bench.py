@@ -900,6 +900,22 @@ def main():
                     "note": "BASELINE configs[4] per-GPU workload in a separate process (python bench.py --workload cfg5_long_traj_bs32 --precision bf16); not the headline"}
             except Exception as e:
                 out.setdefault("variants", {})["cfg5_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+            # the END-TO-END step includes the H2D of the batch (utils/utils_init.py:199-207).  Three short child runs of the same
+            # workload: the batch uploaded under the previous step (overlap), the compact form expanded on the device, and -- SURVEY 8(f) rank 1 --
+            # the loss-aware heads (LM / image logits only where the loss reads them: same losses and gradients).  NOT the headline.
+            for tag, extra, note in (("h2d_overlap", ["--h2d", "overlap"], "batch re-uploaded from pinned host memory every step on a copy stream under the previous step"),
+                                     ("h2d_compact", ["--h2d", "compact"], "compact batch (distinct frames once, un-masked tokens) uploaded every step, options expanded and masked on the device"),
+                                     ("loss_aware_heads", ["--loss-aware-heads"], "decoder / image-head logits only at the positions the losses read (identical losses and gradients)")):
+                try:
+                    import subprocess
+                    torch.cuda.empty_cache()
+                    cmd = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--no-variants", "--no-cpu-baseline", "--no-kernel-timing",
+                           "--host-probe", "0", "--steps", "8", "--warmup", "3"] + extra
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+                    c = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                    out.setdefault("variants", {})[tag] = {"value": c["value"], "unit": "pairs/s", "ms_per_step": c["ms_per_step"], "note": note + "; separate process; not the headline"}
+                except Exception as e:
+                    out.setdefault("variants", {})[tag] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not dp_wrap and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.workload)
     if rank == 0:

@@ -109,7 +109,7 @@ int ytvln_gemm_sk_plan(int M, int N, int K, int transA, int epilogue, int* use, 
                        int* workgroups);
 /* Diagnostics: when `buffer` is non-NULL every workgroup of a persistent launch writes 16 s_memrealtime stamps (100 MHz) to
  * buffer[16 * workgroup + i]: 0 start, 1 ticket drawn, 2 first operands in LDS, then (main loop done, epilogue issued) per piece, 15 end.
- * The buffer must hold 16 * 256 uint64; NULL switches the stamps off (default). */
+ * The buffer must hold 16 * 1024 uint64 (a launch has at most 2 workgroups per CU); NULL switches the stamps off (default). */
 int ytvln_gemm_probe(unsigned long long* buffer);
 
 /* out[b, n] = sum over the b-th block of `rows_per_block` rows of x[:, n].  out is [ceil(M/rows_per_block), N] with

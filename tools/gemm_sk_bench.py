@@ -15,7 +15,8 @@ shapes = {"img": IMG, "text": TEXT, "all": IMG + TEXT}[which]
 ITERS = int(os.environ.get("ITERS", "20"))
 CONFIGS = [("old", dict(GEMM_SK=0)), ("dp4", dict(GEMM_SK=2, GEMM_SK_TILE=4)), ("sk4", dict(GEMM_SK=3, GEMM_SK_TILE=4)),
            ("dp3", dict(GEMM_SK=2, GEMM_SK_TILE=3)), ("sk3", dict(GEMM_SK=3, GEMM_SK_TILE=3)),
-           ("old4", dict(GEMM_SK=0, GEMM_TILE=4)), ("old0", dict(GEMM_SK=0, GEMM_TILE=0)), ("sk4g1", dict(GEMM_SK=3, GEMM_SK_TILE=4, GEMM_SK_GROUPS=1))]
+           ("old4", dict(GEMM_SK=0, GEMM_TILE=4)), ("old0", dict(GEMM_SK=0, GEMM_TILE=0)), ("sk0", dict(GEMM_SK=3, GEMM_SK_TILE=0)),
+           ("dp0", dict(GEMM_SK=2, GEMM_SK_TILE=0)), ("sk0g1", dict(GEMM_SK=3, GEMM_SK_TILE=0, GEMM_SK_GROUPS=1))]
 if os.environ.get("CONFIGS"):
     CONFIGS = [c for c in CONFIGS if c[0] in os.environ["CONFIGS"].split(",")]
 DEFAULTS = dict(GEMM_SK=1, GEMM_SK_TILE=-1, GEMM_SK_GROUPS=8, GEMM_TILE=-1)
@@ -36,7 +37,8 @@ def timed(fn, iters=ITERS):
     return e0.elapsed_time(e1) / iters * 1000
 
 
-probe = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
+NWG = 1024
+probe = torch.zeros(NWG * 16, dtype=torch.int64, device=dev)
 PASSES = int(os.environ.get("PASSES", "3"))
 hot_a, hot_b = torch.randn(8192, 8192, device=dev), torch.randn(8192, 8192, device=dev)
 
@@ -81,7 +83,8 @@ for (M, N, K, tb) in shapes:
             probe.zero_(); torch.cuda.synchronize()
             go(); torch.cuda.synchronize()
             lib.ytvln_gemm_probe(None)
-            p = probe.view(256, 16).cpu().numpy().astype(np.float64) / 100.0      # us
+            p = probe.view(NWG, 16).cpu().numpy().astype(np.float64) / 100.0      # us
+            p = p[p[:, 0] > 0]
             t0 = p[:, 0].min()
             start, tick, first, end = p[:, 0] - t0, p[:, 1] - p[:, 0], p[:, 2] - p[:, 1], p[:, 15] - t0
             pm, pe = p[:, 3] - p[:, 2], p[:, 4] - p[:, 3]           # first piece: main loop, epilogue issue

@@ -139,6 +139,38 @@ __device__ __forceinline__ float dgelu_erf(float x) {
     return cdf + x * pdf;
 }
 
+// ---- memory operations of the interior epilogue, written out: scalar row base + one 32-bit per-lane byte offset -------------------------------
+// (hipcc turns the C++ form of "uniform pointer + per-lane offset" into 64-bit per-lane address arithmetic or, through integer casts, into FLAT
+// accesses; the saddr form needs no address registers at all.)  Loads issued this way are invisible to the compiler's s_waitcnt insertion:
+// epi_wait<N>() is the explicit wait and names the loaded registers so that no use can be scheduled above it.  The leading `s_nop 4`: a scalar
+// base that the compiler has just produced with a VALU instruction (v_readfirstlane, or v_readlane when it reloads a spilled SGPR) needs five
+// wait states before a memory instruction may read it, and the hazard recogniser does not look inside inline asm (round 5: wild addresses,
+// "memory aperture violation", exactly in the epilogues with enough scalar pressure to spill).
+// a wave-uniform pointer pinned into scalar registers (callers whose wave index is not provably uniform to the compiler, e.g. tid >> 6)
+template <class T>
+__device__ __forceinline__ T* scalar_ptr(T* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void epi_store(uint32_t voff, float v, const void* sbase) {
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void epi_load(float& d, uint32_t voff, const void* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+// 2-byte forms for bf16 rows (the bf16-resident GEMM's C and aux): the value sits in the low half of the register
+__device__ __forceinline__ void epi_store_short(uint32_t voff, uint32_t v, const void* sbase) {
+    asm volatile("s_nop 4\n\tglobal_store_short %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void epi_load_ushort(float& d, uint32_t voff, const void* sbase) {      // d receives the zero-extended 16 bits (as raw bits)
+    asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void epi_wait(float (&a)[4], float (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
 // XCD-aware bijective remap of a linear workgroup id (8 XCDs, round-robin dispatch): consecutive remapped ids share an
 // XCD (and therefore an L2).  cdna guide T1 (bijective form).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -623,7 +623,7 @@ extern "C" int ytvln_gemm_sk_plan(int M, int N, int K, int transA, int epilogue,
     const SkPlan sp = plan_sk(M, N, (int)cdiv(K, BK) * BK, transA, epilogue, true, false);
     const Plan plan = plan_gemm(M, N, K, epilogue, true, false, transA != 0);
     *use = sp.use && (opt(OPT_GEMM_SK) >= 2 || sp.cost < 0.98 * plan_cost(M, N, K, plan.tile, plan.splits, epilogue, false, transA != 0));
-    *tile_m = 256; *tile_n = sp.tile == 4 ? 256 : 128; *whole_tiles = sp.dp; *workgroups = sp.G;
+    *tile_m = sp.tile == 0 ? 128 : 256; *tile_n = sp.tile == 4 ? 256 : 128; *whole_tiles = sp.dp; *workgroups = sp.G;
     return 0;
 }
 

@@ -25,6 +25,7 @@
 // gradients, as ytvln_gemm_f32_rowsum).  Shapes the fast path cannot take (unaligned operands) run a small generic kernel.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace ytvln {
 
@@ -197,11 +198,96 @@ __device__ __forceinline__ void bf_epilogue_body(const BfArgs& g, f32x16 (&acc)[
     }
 }
 
+// Interior tiles: the same arithmetic with scalar row bases + ONE per-lane byte offset per matrix and hand-counted loads (gemm_tiles.h
+// epilogue_interior has the story: the per-lane 64-bit pointers of the generic body made hipcc spill beside the 128 accumulators of a 256x256
+// tile, and every scratch reload waited for all stores in flight).  C is bf16 (2-byte stores) or fp32; aux is bf16.
+template <int TM, int TN, int EPI, bool BETA, typename CT>
+__device__ __forceinline__ void bf_epilogue_interior(const BfArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half) {
+    constexpr bool AUX_IN = EPI == YTVLN_EPI_MUL_DGELU || EPI == YTVLN_EPI_MUL_DRELU;
+    constexpr bool C16 = std::is_same<CT, bf16_t>::value;
+    constexpr int NL = (AUX_IN ? 4 : 0) + (BETA ? 4 : 0), NST = 4, G = TN * TM * 4;
+    constexpr int CB = (int)sizeof(CT);
+    const uint32_t vc = (uint32_t)(((int64_t)(4 * half) * g.ldc + l31) * CB);
+    const uint32_t vx = (uint32_t)(((int64_t)(4 * half) * g.ldaux + l31) * 2);
+    const char* const cb = scalar_ptr(reinterpret_cast<const char*>(reinterpret_cast<CT*>(g.C) + (int64_t)row0 * g.ldc + col0));
+    const char* const xb = (EPI != YTVLN_EPI_NONE && EPI != YTVLN_EPI_RELU && g.aux) ? scalar_ptr(reinterpret_cast<const char*>(g.aux + (int64_t)row0 * g.ldaux + col0)) : nullptr;
+    const int64_t cs = g.ldc * CB, xs = g.ldaux * 2;
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = g.bias ? g.bias[col0 + 32 * j + l31] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]));
+    float ax[2][4] = {}, old[2][4] = {};
+    auto row_c = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; const char* p = cb + (int64_t)(32 * i + 8 * q) * cs + 32 * CB * j; asm volatile("" : "+s"(p)); return p; };
+    auto row_x = [&](int gi) { const int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4; const char* p = xb + (int64_t)(32 * i + 8 * q) * xs + 64 * j; asm volatile("" : "+s"(p)); return p; };
+    auto loads = [&](auto gc) {
+        constexpr int gi = decltype(gc)::value;
+        if constexpr (AUX_IN) {
+            const char* const px = row_x(gi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) epi_load_ushort(ax[gi & 1][u], vx, px + u * xs);
+        }
+        if constexpr (BETA) {
+            const char* const pc = row_c(gi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (C16) epi_load_ushort(old[gi & 1][u], vc, pc + u * cs);
+                else epi_load(old[gi & 1][u], vc, pc + u * cs);
+            }
+        }
+    };
+    if constexpr (NL > 0) loads(std::integral_constant<int, 0>{});
+    static_for<G>([&](auto gc) {
+        constexpr int gi = decltype(gc)::value;
+        constexpr int j = gi / (TM * 4), i = (gi / 4) % TM, q = gi % 4;
+        if constexpr (NL > 0) {
+            if constexpr (gi + 1 < G) loads(std::integral_constant<int, gi + 1>{});
+            epi_wait<(gi > 0 ? NST : 0) + (gi + 1 < G ? NL : 0)>(ax[gi & 1], old[gi & 1]);
+        }
+        const char* const pc = row_c(gi);
+        const char* const px = (EPI == YTVLN_EPI_GELU && xb) ? row_x(gi) : nullptr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = acc[i][j][4 * q + u] + bv[j];
+            if (EPI == YTVLN_EPI_GELU) {
+                if (px) epi_store_short(vx, f2bf(v), px + u * xs);
+                v = gelu_erf(v);
+            } else if (EPI == YTVLN_EPI_RELU) {
+                v = fmaxf(v, 0.f);
+            } else if (EPI == YTVLN_EPI_MUL_DGELU) {
+                v *= dgelu_erf(bf2f(__float_as_uint(ax[gi & 1][u])));
+            } else if (EPI == YTVLN_EPI_MUL_DRELU) {
+                v = bf2f(__float_as_uint(ax[gi & 1][u])) > 0.f ? v : 0.f;
+            }
+            if (BETA) v += g.beta * (C16 ? bf2f(__float_as_uint(old[gi & 1][u])) : old[gi & 1][u]);
+            if constexpr (C16) epi_store_short(vc, f2bf(v), pc + u * cs);
+            else epi_store(vc, v, pc + u * cs);
+        }
+    });
+}
+
 template <int TM, int TN, typename CT>
 __device__ __forceinline__ void bf_epilogue(const BfArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half, int split) {
     const bool interior = row0 + 32 * TM <= g.M && col0 + 32 * TN <= g.N;
     if (g.splits > 1) {      // raw fp32 partial sums; bias / beta / rounding are applied by bf_splitk_reduce_kernel in a fixed order
         float* w = g.ws + (int64_t)split * g.M * g.N;
+        if (interior) {          // scalar row bases + one per-lane offset
+            const uint32_t vw = (uint32_t)(((int64_t)(4 * half) * g.N + l31) * 4);
+            const char* const wb = scalar_ptr(reinterpret_cast<const char*>(w + (int64_t)row0 * g.N + col0));
+            const int64_t wsb = (int64_t)g.N * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const char* p = wb + (int64_t)(32 * i + 8 * q) * wsb + 128 * j;
+                        asm volatile("" : "+s"(p));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) epi_store(vw, acc[i][j][4 * q + u], p + u * wsb);
+                    }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = col0 + 32 * j + l31;
@@ -221,7 +307,7 @@ __device__ __forceinline__ void bf_epilogue(const BfArgs& g, f32x16 (&acc)[TM][T
     }
 #define YT_BF_EPI(E)                                                                              \
     case E:                                                                                       \
-        if (interior) bf_epilogue_body<TM, TN, E, true, CT>(g, acc, row0, col0, l31, half);        \
+        if (interior) { if (g.beta != 0.f) bf_epilogue_interior<TM, TN, E, true, CT>(g, acc, row0, col0, l31, half); else bf_epilogue_interior<TM, TN, E, false, CT>(g, acc, row0, col0, l31, half); } \
         else bf_epilogue_body<TM, TN, E, false, CT>(g, acc, row0, col0, l31, half);                \
         break;
     switch (g.epilogue) {
@@ -230,7 +316,7 @@ __device__ __forceinline__ void bf_epilogue(const BfArgs& g, f32x16 (&acc)[TM][T
         YT_BF_EPI(YTVLN_EPI_MUL_DGELU)
         YT_BF_EPI(YTVLN_EPI_MUL_DRELU)
         default:
-            if (interior) bf_epilogue_body<TM, TN, YTVLN_EPI_NONE, true, CT>(g, acc, row0, col0, l31, half);
+            if (interior) { if (g.beta != 0.f) bf_epilogue_interior<TM, TN, YTVLN_EPI_NONE, true, CT>(g, acc, row0, col0, l31, half); else bf_epilogue_interior<TM, TN, YTVLN_EPI_NONE, false, CT>(g, acc, row0, col0, l31, half); }
             else bf_epilogue_body<TM, TN, YTVLN_EPI_NONE, false, CT>(g, acc, row0, col0, l31, half);
             break;
     }

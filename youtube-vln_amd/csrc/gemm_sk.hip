@@ -57,8 +57,8 @@ __device__ __forceinline__ void wait16(f32x4 (&b)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, bool SK>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_sk_kernel(const GemmArgs g, const SkArgs sk) {
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, bool SK, int WPS = 2>
+__global__ __launch_bounds__(NW * 64, WPS) void gemm_sk_kernel(const GemmArgs g, const SkArgs sk) {
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
     constexpr int NS = 2;
@@ -310,21 +310,31 @@ int sk_num_cus() {
     return n;
 }
 
-// us per 32-deep k-tile at the CU-exclusive rate (gemm.hip plan_cost: 256x256 8.0, 256x128 4.16) and the fixed costs of a persistent launch
-static double sk_tk(int tile) { return tile == 4 ? 8.0 : 4.16; }
+// tile codes as in gemm.hip's planner: 0 = 128x128 (8 waves of 32x64, TWO workgroups per CU: 32 accumulator registers per lane, 64 KB of LDS),
+// 3 = 256x128, 4 = 256x256 (8 waves, one workgroup per CU)
+static int sk_bm(int tile) { return tile == 0 ? 128 : 256; }
+static int sk_bn(int tile) { return tile == 4 ? 256 : 128; }
+static int sk_per_cu(int tile) { return tile == 0 ? 2 : 1; }
+// us per 32-deep k-tile of ONE workgroup with the CU fully occupied (round-5 timelines: 256x256 7.7-8.3 in the persistent kernel against 7.5 in the
+// launch-per-tile one -- scalar-register pressure puts lane reads of spilled scalars into its main loop; 256x128 4.5; 128x128: 2.06 per CU = 4.12 per
+// workgroup when two share it)
+static double sk_tk(int tile) { return tile == 4 ? 8.0 : tile == 3 ? 4.5 : 4.12; }
 
 SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, bool x3) {
     SkPlan p = {0, 4, 1, 0, 8, 0.0};
     const int mode = opt(OPT_GEMM_SK);              // 0 off, 1 planner, 2 force DP, 3 force SK
     if (!mode || !fast || x3 || transA || M < 256 || N < 128 || Kloop % BK) return p;
-    const int G = sk_num_cus(), nk = Kloop / BK;
+    const int nk = Kloop / BK;
     const int ngroups = opt(OPT_GEMM_SK_GROUPS) == 1 ? 1 : 8;
     const int force_tile = opt(OPT_GEMM_SK_TILE);
     double best = 1e30;
-    for (int tile = 3; tile <= 4; ++tile) {
+    static const int tiles[3] = {0, 3, 4};
+    for (int ti = 0; ti < 3; ++ti) {
+        const int tile = tiles[ti];
         if (force_tile >= 0 && tile != force_tile) continue;
-        const int bm = 256, bn = tile == 4 ? 256 : 128;
+        const int bm = sk_bm(tile), bn = sk_bn(tile);
         if (N < bn) continue;
+        const int G = sk_num_cus() * sk_per_cu(tile);
         const int ntiles = (int)(cdiv(M, bm) * cdiv(N, bn));
         if (ntiles < 2 * ngroups) continue;
         const int gsize = G / ngroups;
@@ -334,9 +344,9 @@ SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, boo
             const double iters = dp ? (double)cdiv(ntg, gsize) * nk : (double)cdiv((int64_t)ntg * nk, gsize);
             if (!dp && (iters < 4 || (double)ntg * nk * gsize >= 2147483648.0 || (int64_t)(ntiles / ngroups) * nk < gsize)) continue;
             const double tile_bytes = (double)bm * bn * 4.0;
-            // DP: ~2 us of un-overlapped epilogue per tile; SK: one partial dump and, for the heads, (pieces - 1) partial reads at ~150 GB/s
+            // DP: ~2 us of un-overlapped epilogue per tile; SK: one partial dump and, for the heads, the own tile + (pieces - 1) partial reads at ~100 GB/s
             const double pieces = dp ? 1.0 : std::max(1.0, (double)nk / iters + 1.0);
-            double t = 6.0 + iters * sk_tk(tile) + (dp ? 2.0 * cdiv(ntg, gsize) : 3.0 + tile_bytes / 150e3 * pieces);
+            double t = 6.0 + iters * sk_tk(tile) + (dp ? 2.0 * cdiv(ntg, gsize) : 3.0 + tile_bytes / 100e3 * (pieces + 1.0));
             if ((epilogue != YTVLN_EPI_NONE)) t += 3.0 * (dp ? (double)cdiv(ntg, gsize) : 1.0);
             if (t < best) { best = t; p.use = 1; p.tile = tile; p.dp = dp; p.G = G; p.ngroups = ngroups; p.cost = t; }
         }
@@ -346,24 +356,23 @@ SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, boo
 
 int64_t sk_workspace_elems(const SkPlan& p) {
     if (!p.use || p.dp) return 0;
-    const int bn = p.tile == 4 ? 256 : 128;
-    return (int64_t)2 * p.G * 256 * bn;
+    return (int64_t)2 * p.G * sk_bm(p.tile) * sk_bn(p.tile);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WPS>
 static void sk_launch_tile(const GemmArgs& g, const SkArgs& sk, int transB, hipStream_t s) {
     const dim3 grid(sk.G), blk(512);
     if (sk.dp) {
-        if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32, false>), grid, blk, 0, s, g, sk);
-        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32, false>), grid, blk, 0, s, g, sk);
+        if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32, false, WPS>), grid, blk, 0, s, g, sk);
+        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32, false, WPS>), grid, blk, 0, s, g, sk);
     } else {
-        if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32, true>), grid, blk, 0, s, g, sk);
-        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32, true>), grid, blk, 0, s, g, sk);
+        if (transB) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, true, 8, 32, true, WPS>), grid, blk, 0, s, g, sk);
+        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, true, false, 8, 32, true, WPS>), grid, blk, 0, s, g, sk);
     }
 }
 
 void sk_launch(GemmArgs& g, const SkPlan& p, int transB, float* partials, unsigned* ctl, hipStream_t s) {
-    const int bm = 256, bn = p.tile == 4 ? 256 : 128;
+    const int bm = sk_bm(p.tile), bn = sk_bn(p.tile);
     g.tiles_m = (int)cdiv(g.M, bm);
     g.tiles_n = (int)cdiv(g.N, bn);
     g.ntiles = g.tiles_m * g.tiles_n;
@@ -378,8 +387,9 @@ void sk_launch(GemmArgs& g, const SkPlan& p, int transB, float* partials, unsign
     sk.partials = partials;
     sk.ctl = ctl;
     sk.probe = g_probe;
-    if (p.tile == 4) sk_launch_tile<256, 256>(g, sk, transB, s);
-    else sk_launch_tile<256, 128>(g, sk, transB, s);
+    if (p.tile == 4) sk_launch_tile<256, 256, 2>(g, sk, transB, s);
+    else if (p.tile == 3) sk_launch_tile<256, 128, 2>(g, sk, transB, s);
+    else sk_launch_tile<128, 128, 4>(g, sk, transB, s);
 }
 
 }  // namespace ytvln

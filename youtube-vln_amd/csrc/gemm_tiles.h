@@ -187,31 +187,6 @@ __device__ __forceinline__ void epilogue_body(const GemmArgs& g, f32x16 (&acc)[T
 // 64-bit pointer per row group alive next to the 128 accumulators; hipcc then spills a handful of them and -- scratch reloads and global stores
 // share the in-order vmcnt counter -- every reload waits for ALL stores issued before it: ~30 store round trips per 256x256 tile (round 5
 // timeline: 29 us for the epilogue of a 256x256 tile against 4 us for a 256x128 one; this was the launch-per-tile kernel's 25 us "fixed cost").
-// ---- memory operations of the interior epilogue, written out: scalar row base + one 32-bit per-lane byte offset -------------------------------
-// (hipcc turns the C++ form of "uniform pointer + per-lane offset" into 64-bit per-lane address arithmetic or, through integer casts, into FLAT
-// accesses; the saddr form needs no address registers at all.)  Loads issued this way are invisible to the compiler's s_waitcnt insertion:
-// epi_wait<N>() is the explicit wait and names the loaded registers so that no use can be scheduled above it.  The leading `s_nop 4`: a scalar
-// base that the compiler has just produced with a VALU instruction (v_readfirstlane, or v_readlane when it reloads a spilled SGPR) needs five
-// wait states before a memory instruction may read it, and the hazard recogniser does not look inside inline asm (round 5: wild addresses,
-// "memory aperture violation", exactly in the epilogues with enough scalar pressure to spill).
-// a wave-uniform pointer pinned into scalar registers (callers whose wave index is not provably uniform to the compiler, e.g. tid >> 6)
-template <class T>
-__device__ __forceinline__ T* scalar_ptr(T* p) {
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ void epi_store(uint32_t voff, float v, const void* sbase) {
-    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void epi_load(float& d, uint32_t voff, const void* sbase) {
-    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void epi_wait(float (&a)[4], float (&b)[4]) {
-    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
-}
-
 // Interior tiles (every row and column of the wave's sub-tile inside the matrix): the arithmetic of epilogue_body with the addressing rebuilt for
 // the register file.  row0 / col0 are wave-uniform, so every access is (scalar base of its row) + ONE per-lane byte offset that is the same for
 // the whole epilogue (4 * half rows down, l31 columns right).  The generic body keeps 64-bit per-lane pointers alive next to the 128 accumulators
@@ -296,8 +271,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        epi_store(vw, acc[i][j][r], wb + (int64_t)(32 * i + (r & 3) + 8 * (r >> 2)) * wsb + 128 * j);
+                    for (int q = 0; q < 4; ++q) {
+                        const char* p = wb + (int64_t)(32 * i + 8 * q) * wsb + 128 * j;
+                        asm volatile("" : "+s"(p));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) epi_store(vw, acc[i][j][4 * q + u], p + u * wsb);
+                    }
             return;
         }
 #pragma unroll
