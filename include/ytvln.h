@@ -256,6 +256,9 @@ typedef struct ytvln_attn_problem {
     float p_drop;
     int32_t reserved;
     int64_t site;
+    void* keep;      /* bf16 entry points with p_drop > 0: the keep decisions of the dropout, ytvln_attn_keep_bytes(N, heads, Tq, Tk) bytes, 128-byte
+                        aligned -- WRITTEN by ytvln_attn_fwd_bf16 (16 64-bit lane masks per 32x32 block of scores), READ by ytvln_attn_bwd_bf16 of the
+                        same problem; ignored by the fp32 entry points (they regenerate the hash) and when p_drop == 0 (may be NULL) */
 } ytvln_attn_problem;
 int ytvln_attn_fwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
                         const int64_t* rng, void* stream);
@@ -266,6 +269,7 @@ int ytvln_attn_bwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b
  * with fp32 accumulation and fp32 softmax, the transposed operands (V^T.P^T, K^T.dS^T, Q^T.dS, dO^T.P) are gathered from the row-major LDS
  * tiles by ds_read_b64_tr_b16.  `b` may be NULL (one problem: self-attention) or the second direction of BertBiAttention.  Head dimension
  * 64 or 128. */
+int64_t ytvln_attn_keep_bytes(int N, int heads, int Tq, int Tk);
 int ytvln_attn_fwd_bf16(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
                         const int64_t* rng, void* stream);
 int ytvln_attn_bwd_bf16(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,

@@ -14,7 +14,12 @@
 //     contraction over d) and ds_read_b64_tr_b16 of [4 rows][16 columns] blocks (A operand of V^T.P^T, contraction over the rows: the hardware
 //     transpose delivers the 8 rows a lane feeds to the matrix instruction -- no transposed copy of V, K, Q or dO exists anywhere);
 //   * outputs leave as bf16, 8 bytes per lane (4 consecutive head columns of the lane's own row).
-// Dropout of the probabilities: the same per-score hash as attention.hip (common.h: attn_drop_hash), regenerated in backward.
+// Dropout of the probabilities: the same per-score hash as attention.hip (common.h: attn_drop_hash), drawn ONCE, in the forward kernel.  The
+// keep decisions are the forward's compare results -- for accumulator register r of a (32 queries x 32 keys) block a 64-bit lane mask (lane =
+// query + 32 half, key = bkrow(r, half)) -- and they are written out as such: 16 masks = 128 bytes per block.  dQ has the forward's lane layout
+// and reads a block's masks with scalar loads straight into the select operand of v_cndmask; dK/dV (key on the lane, queries down the
+// registers) reads ONE 8-byte mask per lane and block and tests a bit per score.  (Round 4 regenerated the hash in both backward kernels:
+// ~10 of the ~20 vector instructions per score there.)
 // Head dimensions 64 and 128 (unpadded); sequences up to 8192 keys / queries (the mask / lse rows live in LDS).
 #include "common.h"
 #include <algorithm>
@@ -39,6 +44,7 @@ struct BAttnArgs {
     int N, heads, Tq, Tk, d;
     float scale, p_drop;
     const int64_t* rng; int64_t site;
+    uint64_t* keep;              // dropout keep decisions of the forward: [N * heads][query block][key tile][16] 64-bit lane masks (see battn_fwd_body)
 };
 struct BAttnLaunch { BAttnArgs p[2]; int nb0, gx0, gx1; };
 
@@ -223,6 +229,7 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
         for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
     float m = -INFINITY, l = 0.f;
     const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));
+    uint64_t* const kblock = (DROP && a.keep) ? a.keep + (((int64_t)n * a.heads + h) * ((a.Tq + 31) >> 5) + bx) * ntiles * 16 : nullptr;
 
     auto tile = [&](auto FIRST_T, auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
@@ -261,12 +268,19 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
 #pragma unroll
         for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
         l += b_halves_sum(ps);
-        if (DROP) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t bits = attn_drop_hash((uint32_t)(j0 + bkrow(r, half)), dlo, key);
-                P[r] = bits >= thr ? P[r] * ik : 0.f;
-            }
+        if (DROP && a.keep) {
+            uint32_t mlo = 0, mhi = 0;          // lane r (< 16) collects mask r
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const bool kp = attn_drop_hash((uint32_t)(j0 + bkrow(r, half)), dlo, key) >= thr;
+                const uint64_t m = __ballot(kp);
+                P[r] = kp ? P[r] * ik : 0.f;
+                uint32_t lo = mlo, hi = mhi;
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)m), "n"(r));          // (one scalar operand per vector instruction: the lane is an inline constant)
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(m >> 32)), "n"(r));
+                mlo = lo; mhi = hi;
+            });
+            if (lane < 16) kblock[(int64_t)t * 16 + lane] = ((uint64_t)mhi << 32) | mlo;
         }
         const bf16x8 Pb[2] = {bpack8(P), bpack8(P + 8)};
         if (more) b_wait<PC>();                                              // V(t); K(t+1) may still be on its way
@@ -343,11 +357,17 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dQ[c][r] = 0.f;
-    const uint32_t dlo = (uint32_t)sidx;
+    const uint64_t* const kblock = (DROP && a.keep) ? a.keep + (((int64_t)n * a.heads + h) * ((a.Tq + 31) >> 5) + bx) * ntiles * 16 : nullptr;
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
     auto tile = [&](auto FIRST_T, auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
         const int j0 = t * 32;
+        u32x16 ma, mb;          // this block's 16 keep masks (2 dwords each), by scalar loads: they do not touch the counted vmcnt queue
+        if (DROP && kblock) {
+            const uint64_t* kp = scalar_ptr(kblock + (int64_t)t * 16);          // (wave-uniform; s_nop: a scalar the VALU has just written needs wait states before SMEM reads it)
+            asm volatile("s_nop 4\n\ts_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(ma), "=&s"(mb) : "s"(kp) : "memory");
+        }
         // V(t); K(t) may still be on its way (first tile: the prologue's last loads have been consumed, so everything has landed)
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else b_wait<PC>();
@@ -367,6 +387,7 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
 #pragma unroll
         for (int s = 0; s < NS; ++s) S = MFMA_B(T::kc(Ks, l31, half, s), Qr[s], S);
         float dS[16];
+        if (DROP && kblock) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ma), "+s"(mb) : : "memory");
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 mk = blds4(Mrow + j0 + 8 * g + 4 * half);
@@ -376,7 +397,11 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
                 const int r = 4 * g + u;
                 const float p = __expf(bscore(S[r], a.scale, mkv[u]) - lse);
                 float dp = dP[r];
-                if (DROP) dp = attn_drop_hash((uint32_t)(j0 + bkrow(r, half)), dlo, key) >= thr ? dp * ik : 0.f;
+                if (DROP && kblock) {          // dp = keep ? dp / (1 - p_drop) : 0 -- the mask of register r is the select operand itself
+                    const uint64_t m = r < 8 ? ((uint64_t)ma[2 * (r & 7) + 1] << 32) | ma[2 * (r & 7)] : ((uint64_t)mb[2 * (r & 7) + 1] << 32) | mb[2 * (r & 7)];
+                    const float scaled = dp * ik;
+                    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(dp) : "v"(scaled), "s"(m));
+                }
                 dS[r] = p * (dp - dl);
             }
         }
@@ -445,9 +470,19 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accV[c][r] = 0.f; accK[c][r] = 0.f; }
 
+    // keep bits (see the header): this lane's key is column c = l31 of the block; in the forward's layout that key sat in register rf of half hf
+    const int kc = l31, hf = (kc >> 2) & 1, rf = (kc & 3) + 4 * (kc >> 3);
+    const int nkt = (a.Tk + 31) >> 5;
+    const uint64_t* const kcol = (DROP && a.keep) ? a.keep + ((((int64_t)n * a.heads + h) * nqt) * nkt + bx) * 16 + rf : nullptr;
+
     auto tile = [&](auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool more = decltype(MORE_T)::value;
         const int i0 = t * 32;
+        uint32_t kw = 0;          // bit (r & 3) + 8 (r >> 2) of kw = keep decision of query row bkrow(r, half) of this tile for this lane's key
+        if (DROP && kcol) {
+            const uint64_t mk64 = kcol[(int64_t)t * nkt * 16];
+            kw = (uint32_t)(hf ? (mk64 >> 32) : mk64) >> (4 * half);
+        }
         b_wait<PC>();           // Q(t); dO(t) may still be on its way (first tile: the prologue has drained the queue)
         f32x16 S;
 #pragma unroll
@@ -471,8 +506,8 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
                 const int r = 4 * g + u;
                 const float p = __expf(bscore(S[r], a.scale, mk) - lsv[u]);
                 float pk = p, dp = dP[r];
-                if (DROP) {
-                    const bool keep = attn_drop_hash((uint32_t)kj, (uint32_t)(srow + i0 + bkrow(r, half)), key) >= thr;
+                if (DROP && kcol) {
+                    const bool keep = (kw & (1u << ((r & 3) + 8 * (r >> 2)))) != 0;
                     pk = keep ? p * ik : 0.f;
                     dp = keep ? dp * ik : 0.f;
                 }
@@ -530,6 +565,7 @@ static int bcheck(const char* who, const BAttnArgs& a) {
     YT_REQUIRE((((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) & 15) == 0, "%s: q/k/v must be 16-byte aligned", who);
     YT_REQUIRE(a.p_drop >= 0.f && a.p_drop < 1.f, "%s: p_drop out of range", who);
     YT_REQUIRE(!(a.p_drop > 0.f) || a.rng, "%s: dropout needs rng state", who);
+    YT_REQUIRE(!(a.p_drop > 0.f) || (a.keep && ((uintptr_t)a.keep & 127) == 0), "%s: dropout needs the keep-mask buffer (ytvln_attn_keep_bytes, 128-byte aligned)", who);
     YT_REQUIRE(a.Tk <= 8192 && a.Tq <= 8192, "%s: sequence too long for the LDS-resident mask / lse rows", who);
     YT_REQUIRE((int64_t)a.N * std::max(a.Tq, a.Tk) * std::max(std::max(a.ldq, a.ldk), std::max(a.ldv, a.ldo)) < (1ll << 32),
                "%s: tensor too large for 32-bit element offsets", who);
@@ -617,6 +653,12 @@ static void bfill(BAttnArgs& a, const ytvln_attn_problem& pr, int N, int heads, 
     a.out = (bf16_t*)pr.ctx; a.lse_out = pr.lse; a.dq = (bf16_t*)pr.dq; a.dk = (bf16_t*)pr.dk; a.dv = (bf16_t*)pr.dv;
     a.ldq = pr.ldq; a.ldk = pr.ldk; a.ldv = pr.ldv; a.ldo = pr.ldo; a.lddq = pr.lddq; a.lddk = pr.lddk; a.lddv = pr.lddv;
     a.N = N; a.heads = heads; a.Tq = pr.Tq; a.Tk = pr.Tk; a.d = d; a.scale = scale; a.p_drop = pr.p_drop; a.rng = rng; a.site = pr.site;
+    a.keep = (uint64_t*)pr.keep;
+}
+
+extern "C" int64_t ytvln_attn_keep_bytes(int N, int heads, int Tq, int Tk) {
+    if (N <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return 0;
+    return (int64_t)N * heads * cdiv(Tq, 32) * cdiv(Tk, 32) * 128;
 }
 
 extern "C" int ytvln_attn_fwd_bf16(const ytvln_attn_problem* pa, const ytvln_attn_problem* pb, int N, int heads, int d, float scale,

@@ -27,7 +27,7 @@ class AttnProblem(C.Structure):
     """`ytvln_attn_problem` of include/ytvln.h."""
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "mask", "ctx_in", "dctx", "lse_in", "ctx", "lse", "delta", "dq", "dk", "dv")] + \
                [(n, C.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddq", "lddk", "lddv")] + \
-               [("Tq", C.c_int32), ("Tk", C.c_int32), ("p_drop", C.c_float), ("reserved", C.c_int32), ("site", C.c_int64)]
+               [("Tq", C.c_int32), ("Tk", C.c_int32), ("p_drop", C.c_float), ("reserved", C.c_int32), ("site", C.c_int64), ("keep", C.c_void_p)]
 
 
 SIGNATURES = {
@@ -45,6 +45,7 @@ SIGNATURES = {
     "ytvln_scatter_add_rows_sorted_f32": [P, I64, P, P, I32, I32, P, I64, P],
     "ytvln_randomize_tokens": [P, P, I64, I32, I64, P, P, P, I64, P, P, P],
     "ytvln_randomize_regions": [P, I64, P, P, I64, I32, I32, P, P, I64, P, P, P],
+    "ytvln_attn_keep_bytes": [I32, I32, I32, I32],
     "ytvln_attn_fwd_bf16": [P, P, I32, I32, I32, F32, P, P],
     "ytvln_attn_bwd_bf16": [P, P, I32, I32, I32, F32, P, P],
     "ytvln_attn_fwd_pair": [P, P, I32, I32, I32, F32, P, P],
@@ -98,7 +99,7 @@ SIGNATURES = {
     "ytvln_rccl_async_error": [P],
     "ytvln_rccl_destroy": [P],
 }
-RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_gemm_sk_ctl_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
+RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_attn_keep_bytes": I64, "ytvln_gemm_sk_ctl_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
 DT_F32, DT_F64, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128

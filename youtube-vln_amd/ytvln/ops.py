@@ -1349,7 +1349,7 @@ def _eptr(t: Optional[Tensor], offset_elems: int = 0):
 
 
 def _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=None, lse=None, ctx_in=None, dctx=None,
-                  lse_in=None, delta=None, dq=None, dq_off=0, lddq=0, dk=None, dk_off=0, lddk=0, dv=None, dv_off=0, lddv=0):
+                  lse_in=None, delta=None, dq=None, dq_off=0, lddq=0, dk=None, dk_off=0, lddk=0, dv=None, dv_off=0, lddv=0, keep=None):
     """One `ytvln_attn_problem` record (include/ytvln.h); q / k / v / ctx / gradients are fp32 or bf16 tensors (offsets in elements)."""
     pr = _lib.AttnProblem()
     pr.q, pr.k, pr.v, pr.mask = _eptr(q, q_off), _eptr(k, k_off), _eptr(v, v_off), _ptr(mask)
@@ -1359,7 +1359,16 @@ def _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, 
     o = ctx if ctx is not None else ctx_in
     pr.ldq, pr.ldk, pr.ldv, pr.ldo, pr.lddq, pr.lddk, pr.lddv = ldq, ldk, ldv, o.shape[-1], lddq, lddk, lddv
     pr.Tq, pr.Tk, pr.p_drop, pr.site = Tq, Tk, float(p), int(site)
+    pr.keep = keep.data_ptr() if keep is not None else None
     return pr
+
+
+def _attn_keep(N, heads, Tq, Tk, p, device):
+    """bf16-resident attention with dropout: the buffer the forward kernel writes its keep decisions to and the backward kernels read them from
+    (`ytvln_attn_problem.keep`); None without dropout."""
+    if not p > 0:
+        return None
+    return torch.empty(int(_lib.load().ytvln_attn_keep_bytes(N, heads, Tq, Tk)), dtype=torch.uint8, device=device)
 
 
 def _attn_launch(backward: bool, bf16: bool, pa, pb, N, heads, d, scale, rng):
@@ -1376,21 +1385,27 @@ def _attn_launch(backward: bool, bf16: bool, pa, pb, N, heads, d, scale, rng):
 def _attn_fwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, N, heads, Tq, Tk, d, scale, p, rng, site):
     lse = torch.empty((N, heads, Tq), dtype=torch.float32, device=out.device)
     if q.dtype == torch.bfloat16:
-        _attn_launch(False, True, _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=out, lse=lse), None,
-                     N, heads, d, scale, rng)
-        return lse
+        keep = _attn_keep(N, heads, Tq, Tk, p, out.device)
+        _attn_launch(False, True, _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx=out, lse=lse, keep=keep),
+                     None, N, heads, d, scale, rng)
+        lse._ytvln_keep = keep          # direct callers hand `lse` to _attn_bwd, which finds the forward's keep decisions here; the autograd
+        return lse                      # functions save the buffer explicitly (a saved tensor is unpacked into a new Python object)
     call("ytvln_attn_fwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), out.shape[-1],
          _ptr(lse), N, heads, Tq, Tk, d, float(scale), float(p), _ptr(rng) if rng is not None else None, int(site), _stream())
     return lse
 
 
 def _attn_bwd(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, out, dout, lse, dq, dq_off, lddq, dk, dk_off, lddk, dv, dv_off,
-              lddv, N, heads, Tq, Tk, d, scale, p, rng, site):
+              lddv, N, heads, Tq, Tk, d, scale, p, rng, site, keep=None):
     delta = torch.empty_like(lse)
     if q.dtype == torch.bfloat16:
+        if keep is None:
+            keep = getattr(lse, "_ytvln_keep", None)
+        if p > 0 and keep is None:
+            raise RuntimeError("bf16 attention backward with dropout needs the keep decisions its forward wrote (pass keep= or the lse tensor _attn_fwd returned)")
         _attn_launch(True, True, _attn_problem(q, q_off, ldq, k, k_off, ldk, v, v_off, ldv, mask, Tq, Tk, p, site, ctx_in=out, dctx=dout,
                                                lse_in=lse, delta=delta, dq=dq, dq_off=dq_off, lddq=lddq, dk=dk, dk_off=dk_off, lddk=lddk,
-                                               dv=dv, dv_off=dv_off, lddv=lddv), None, N, heads, d, scale, rng)
+                                               dv=dv, dv_off=dv_off, lddv=lddv, keep=keep), None, N, heads, d, scale, rng)
         return
     call("ytvln_attn_bwd_f32", _ptr(q, q_off), ldq, _ptr(k, k_off), ldk, _ptr(v, v_off), ldv, _ptr(mask), _ptr(out), _ptr(dout),
          out.shape[-1], _ptr(lse), _ptr(delta), _ptr(dq, dq_off), lddq, _ptr(dk, dk_off), lddk, _ptr(dv, dv_off), lddv, N, heads, Tq,
@@ -1425,8 +1440,9 @@ class SelfAttentionFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(d)
         out = torch.empty((N * T, H), dtype=qkv.dtype, device=qkv.device)
         lse = _attn_fwd(qkv, 0, 3 * H, qkv, H, 3 * H, qkv, 2 * H, 3 * H, mask, out, N, heads, T, T, d, scale, p, rng, site)
+        keep = getattr(lse, "_ytvln_keep", None)
         ctx.meta = (N, T, heads, H, d, scale, p, site)
-        ctx.save_for_backward(qkv, mask, out, lse, rng)
+        ctx.save_for_backward(qkv, mask, out, lse, rng, keep)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
@@ -1434,14 +1450,14 @@ class SelfAttentionFn(torch.autograd.Function):
     def backward(ctx, dout, _dlse):
         if dout is None:
             return (None,) * 8
-        qkv, mask, out, lse, rng = ctx.saved_tensors
+        qkv, mask, out, lse, rng, keep = ctx.saved_tensors
         N, T, heads, H, d, scale, p, site = ctx.meta
         dout = dout if dout.is_contiguous() else dout.contiguous()
         if dout.dtype != qkv.dtype:
             dout = dout.to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         _attn_bwd(qkv, 0, 3 * H, qkv, H, 3 * H, qkv, 2 * H, 3 * H, mask, out, dout, lse, dqkv, 0, 3 * H, dqkv, H, 3 * H, dqkv, 2 * H,
-                  3 * H, N, heads, T, T, d, scale, p, rng, site)
+                  3 * H, N, heads, T, T, d, scale, p, rng, site, keep=keep)
         return dqkv, None, None, None, None, None, None, None
 
 
@@ -1469,19 +1485,21 @@ class CoAttentionFn(torch.autograd.Function):
         lse1 = torch.empty((N, heads, T), dtype=torch.float32, device=q1.device)
         lse2 = torch.empty((N, heads, R), dtype=torch.float32, device=q1.device)
         # both directions in one launch (text queries over regions | region queries over text)
+        keep1 = _attn_keep(N, heads, T, R, p1, q1.device) if bf16 else None
+        keep2 = _attn_keep(N, heads, R, T, p2, q1.device) if bf16 else None
         _attn_launch(False, bf16,
-                     _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx=ctx1, lse=lse1),
-                     _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx=ctx2, lse=lse2),
+                     _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx=ctx1, lse=lse1, keep=keep1),
+                     _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx=ctx2, lse=lse2, keep=keep2),
                      N, heads, d, scale, rng)
         ctx.meta = (N, R, T, heads, Hb, d, scale, p1, p2, site1, site2)
-        ctx.save_for_backward(q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng)
+        ctx.save_for_backward(q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng, keep1, keep2)
         ctx.mark_non_differentiable(lse1, lse2)
         ctx.set_materialize_grads(False)
         return ctx1, ctx2, lse1, lse2
 
     @staticmethod
     def backward(ctx, d1, d2, _a, _b):
-        q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng = ctx.saved_tensors
+        q1, kv1, q2, kv2, mask1, mask2, ctx1, ctx2, lse1, lse2, rng, keep1, keep2 = ctx.saved_tensors
         N, R, T, heads, Hb, d, scale, p1, p2, site1, site2 = ctx.meta
         gq1 = gkv1 = gq2 = gkv2 = None
         if d1 is not None and d2 is not None:       # the usual case: both directions in one launch per kernel
@@ -1491,21 +1509,21 @@ class CoAttentionFn(torch.autograd.Function):
             delta1, delta2 = torch.empty_like(lse1), torch.empty_like(lse2)
             _attn_launch(True, q1.dtype == torch.bfloat16,
                        _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx_in=ctx1, dctx=d1, lse_in=lse1,
-                                     delta=delta1, dq=gq2, lddq=Hb, dk=gkv1, lddk=2 * Hb, dv=gkv1, dv_off=Hb, lddv=2 * Hb),
+                                     delta=delta1, dq=gq2, lddq=Hb, dk=gkv1, lddk=2 * Hb, dv=gkv1, dv_off=Hb, lddv=2 * Hb, keep=keep1),
                        _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx_in=ctx2, dctx=d2, lse_in=lse2,
-                                     delta=delta2, dq=gq1, lddq=Hb, dk=gkv2, lddk=2 * Hb, dv=gkv2, dv_off=Hb, lddv=2 * Hb),
+                                     delta=delta2, dq=gq1, lddq=Hb, dk=gkv2, lddk=2 * Hb, dv=gkv2, dv_off=Hb, lddv=2 * Hb, keep=keep2),
                        N, heads, d, scale, rng)
             return (gq1, gkv1, gq2, gkv2) + (None,) * 11
         if d1 is not None:      # text queries over image keys/values -> dq2, dk1|dv1
             d1 = d1 if d1.is_contiguous() else d1.contiguous()
             gq2, gkv1 = torch.empty_like(q2), torch.empty_like(kv1)
             _attn_bwd(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, ctx1, d1, lse1, gq2, 0, Hb, gkv1, 0, 2 * Hb, gkv1, Hb,
-                      2 * Hb, N, heads, T, R, d, scale, p1, rng, site1)
+                      2 * Hb, N, heads, T, R, d, scale, p1, rng, site1, keep=keep1)
         if d2 is not None:      # image queries over text keys/values -> dq1, dk2|dv2
             d2 = d2 if d2.is_contiguous() else d2.contiguous()
             gq1, gkv2 = torch.empty_like(q1), torch.empty_like(kv2)
             _attn_bwd(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, ctx2, d2, lse2, gq1, 0, Hb, gkv2, 0, 2 * Hb, gkv2, Hb,
-                      2 * Hb, N, heads, R, T, d, scale, p2, rng, site2)
+                      2 * Hb, N, heads, R, T, d, scale, p2, rng, site2, keep=keep2)
         return (gq1, gkv1, gq2, gkv2) + (None,) * 11
 
 
