@@ -258,7 +258,8 @@ typedef struct ytvln_attn_problem {
     int64_t site;
     void* keep;      /* bf16 entry points with p_drop > 0: the keep decisions of the dropout, ytvln_attn_keep_bytes(N, heads, Tq, Tk) bytes, 128-byte
                         aligned -- WRITTEN by ytvln_attn_fwd_bf16 (16 64-bit lane masks per 32x32 block of scores), READ by ytvln_attn_bwd_bf16 of the
-                        same problem; ignored by the fp32 entry points (they regenerate the hash) and when p_drop == 0 (may be NULL) */
+                        same problem; in a two-problem launch BOTH records need one as soon as either has p_drop > 0; ignored by the fp32 entry points (they
+                        regenerate the hash) and by launches without dropout (may be NULL) */
 } ytvln_attn_problem;
 int ytvln_attn_fwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
                         const int64_t* rng, void* stream);

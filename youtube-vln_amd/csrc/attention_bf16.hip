@@ -229,7 +229,8 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
         for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
     float m = -INFINITY, l = 0.f;
     const uint32_t dlo = (uint32_t)((((int64_t)n * a.heads + h) * a.Tq + qi));
-    uint64_t* const kblock = (DROP && a.keep) ? a.keep + (((int64_t)n * a.heads + h) * ((a.Tq + 31) >> 5) + bx) * ntiles * 16 : nullptr;
+    // (a launch with dropout in either of its problems carries a keep buffer for both: the host checks it)
+    uint64_t* const kblock = DROP ? a.keep + (((int64_t)n * a.heads + h) * ((a.Tq + 31) >> 5) + bx) * ntiles * 16 : nullptr;
 
     auto tile = [&](auto FIRST_T, auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
@@ -268,7 +269,7 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
 #pragma unroll
         for (int r = 0; r < 16; ++r) { P[r] = __expf(P[r] - m); ps += P[r]; }
         l += b_halves_sum(ps);
-        if (DROP && a.keep) {
+        if (DROP) {
             uint32_t mlo = 0, mhi = 0;          // lane r (< 16) collects mask r
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -276,8 +277,10 @@ __device__ __forceinline__ void battn_fwd_body(const BAttnArgs& a, const int bx,
                 const uint64_t m = __ballot(kp);
                 P[r] = kp ? P[r] * ik : 0.f;
                 uint32_t lo = mlo, hi = mhi;
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)m), "n"(r));          // (one scalar operand per vector instruction: the lane is an inline constant)
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(m >> 32)), "n"(r));
+                // (one scalar operand per vector instruction: the lane is an inline constant.  s_nop: the mask is a scalar the VALU has just written
+                //  (v_cmp); gfx950 wants two wait states before another vector instruction reads it, and the hazard recogniser does not see into
+                //  inline asm -- without them the low words of most masks of a tile came out wrong, 7 % of the stored bits)
+                asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "n"(r));
                 mlo = lo; mhi = hi;
             });
             if (lane < 16) kblock[(int64_t)t * 16 + lane] = ((uint64_t)mhi << 32) | mlo;
@@ -357,14 +360,14 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dQ[c][r] = 0.f;
-    const uint64_t* const kblock = (DROP && a.keep) ? a.keep + (((int64_t)n * a.heads + h) * ((a.Tq + 31) >> 5) + bx) * ntiles * 16 : nullptr;
+    const uint64_t* const kblock = DROP ? a.keep + (((int64_t)n * a.heads + h) * ((a.Tq + 31) >> 5) + bx) * ntiles * 16 : nullptr;
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
     auto tile = [&](auto FIRST_T, auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
         const int j0 = t * 32;
         u32x16 ma, mb;          // this block's 16 keep masks (2 dwords each), by scalar loads: they do not touch the counted vmcnt queue
-        if (DROP && kblock) {
+        if (DROP) {
             const uint64_t* kp = scalar_ptr(kblock + (int64_t)t * 16);          // (wave-uniform; s_nop: a scalar the VALU has just written needs wait states before SMEM reads it)
             asm volatile("s_nop 4\n\ts_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(ma), "=&s"(mb) : "s"(kp) : "memory");
         }
@@ -387,7 +390,7 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
 #pragma unroll
         for (int s = 0; s < NS; ++s) S = MFMA_B(T::kc(Ks, l31, half, s), Qr[s], S);
         float dS[16];
-        if (DROP && kblock) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ma), "+s"(mb) : : "memory");
+        if (DROP) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ma), "+s"(mb) : : "memory");
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 mk = blds4(Mrow + j0 + 8 * g + 4 * half);
@@ -397,7 +400,7 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
                 const int r = 4 * g + u;
                 const float p = __expf(bscore(S[r], a.scale, mkv[u]) - lse);
                 float dp = dP[r];
-                if (DROP && kblock) {          // dp = keep ? dp / (1 - p_drop) : 0 -- the mask of register r is the select operand itself
+                if (DROP) {          // dp = keep ? dp / (1 - p_drop) : 0 -- the mask of register r is the select operand itself
                     const uint64_t m = r < 8 ? ((uint64_t)ma[2 * (r & 7) + 1] << 32) | ma[2 * (r & 7)] : ((uint64_t)mb[2 * (r & 7) + 1] << 32) | mb[2 * (r & 7)];
                     const float scaled = dp * ik;
                     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(dp) : "v"(scaled), "s"(m));
@@ -473,13 +476,13 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
     // keep bits (see the header): this lane's key is column c = l31 of the block; in the forward's layout that key sat in register rf of half hf
     const int kc = l31, hf = (kc >> 2) & 1, rf = (kc & 3) + 4 * (kc >> 3);
     const int nkt = (a.Tk + 31) >> 5;
-    const uint64_t* const kcol = (DROP && a.keep) ? a.keep + ((((int64_t)n * a.heads + h) * nqt) * nkt + bx) * 16 + rf : nullptr;
+    const uint64_t* const kcol = DROP ? a.keep + ((((int64_t)n * a.heads + h) * nqt) * nkt + bx) * 16 + rf : nullptr;
 
     auto tile = [&](auto MORE_T, const int t) __attribute__((always_inline)) {
         constexpr bool more = decltype(MORE_T)::value;
         const int i0 = t * 32;
         uint32_t kw = 0;          // bit (r & 3) + 8 (r >> 2) of kw = keep decision of query row bkrow(r, half) of this tile for this lane's key
-        if (DROP && kcol) {
+        if (DROP) {
             const uint64_t mk64 = kcol[(int64_t)t * nkt * 16];
             kw = (uint32_t)(hf ? (mk64 >> 32) : mk64) >> (4 * half);
         }
@@ -506,7 +509,7 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
                 const int r = 4 * g + u;
                 const float p = __expf(bscore(S[r], a.scale, mk) - lsv[u]);
                 float pk = p, dp = dP[r];
-                if (DROP && kcol) {
+                if (DROP) {
                     const bool keep = (kw & (1u << ((r & 3) + 8 * (r >> 2)))) != 0;
                     pk = keep ? p * ik : 0.f;
                     dp = keep ? dp * ik : 0.f;
@@ -565,7 +568,6 @@ static int bcheck(const char* who, const BAttnArgs& a) {
     YT_REQUIRE((((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) & 15) == 0, "%s: q/k/v must be 16-byte aligned", who);
     YT_REQUIRE(a.p_drop >= 0.f && a.p_drop < 1.f, "%s: p_drop out of range", who);
     YT_REQUIRE(!(a.p_drop > 0.f) || a.rng, "%s: dropout needs rng state", who);
-    YT_REQUIRE(!(a.p_drop > 0.f) || (a.keep && ((uintptr_t)a.keep & 127) == 0), "%s: dropout needs the keep-mask buffer (ytvln_attn_keep_bytes, 128-byte aligned)", who);
     YT_REQUIRE(a.Tk <= 8192 && a.Tq <= 8192, "%s: sequence too long for the LDS-resident mask / lse rows", who);
     YT_REQUIRE((int64_t)a.N * std::max(a.Tq, a.Tk) * std::max(std::max(a.ldq, a.ldk), std::max(a.ldv, a.ldo)) < (1ll << 32),
                "%s: tensor too large for 32-bit element offsets", who);
@@ -599,6 +601,9 @@ static int blaunch_fwd(BAttnLaunch& b, int np, hipStream_t s) {
     const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
     YT_REQUIRE(total < (1ll << 31), "attn_fwd_bf16: grid too large");
     const size_t lds = (size_t)2 * 32 * a0.d * 2 + (size_t)cdiv(maxTk, 32) * 32 * sizeof(float);
+    for (int i = 0; i < np; ++i)
+        YT_REQUIRE(!drop || (b.p[i].keep && ((uintptr_t)b.p[i].keep & 127) == 0),
+                   "attn_fwd_bf16: a launch with dropout needs a keep buffer (ytvln_attn_keep_bytes, 128-byte aligned) in every problem");
     YT_BLAUNCH(battn_fwd_kernel, lds);
     YT_LAUNCH_CHECK("attn_fwd_bf16");
     return 0;
@@ -619,6 +624,9 @@ static int blaunch_bwd(BAttnLaunch& b, int np, hipStream_t s) {
         drop = drop || a.p_drop > 0.f;
         maxTq = std::max(maxTq, a.Tq); maxTk = std::max(maxTk, a.Tk);
     }
+    for (int i = 0; i < np; ++i)
+        YT_REQUIRE(!drop || (b.p[i].keep && ((uintptr_t)b.p[i].keep & 127) == 0),
+                   "attn_bwd_bf16: a launch with dropout needs the keep buffers its forward wrote in every problem");
     {
         b.gx0 = (int)cdiv(b.p[0].Tq, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32) : 1;

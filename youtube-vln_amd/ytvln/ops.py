@@ -1485,8 +1485,9 @@ class CoAttentionFn(torch.autograd.Function):
         lse1 = torch.empty((N, heads, T), dtype=torch.float32, device=q1.device)
         lse2 = torch.empty((N, heads, R), dtype=torch.float32, device=q1.device)
         # both directions in one launch (text queries over regions | region queries over text)
-        keep1 = _attn_keep(N, heads, T, R, p1, q1.device) if bf16 else None
-        keep2 = _attn_keep(N, heads, R, T, p2, q1.device) if bf16 else None
+        pk = max(p1, p2)          # one launch: dropout in either direction makes the kernels record decisions for both
+        keep1 = _attn_keep(N, heads, T, R, pk, q1.device) if bf16 else None
+        keep2 = _attn_keep(N, heads, R, T, pk, q1.device) if bf16 else None
         _attn_launch(False, bf16,
                      _attn_problem(q2, 0, Hb, kv1, 0, 2 * Hb, kv1, Hb, 2 * Hb, mask1, T, R, p1, site1, ctx=ctx1, lse=lse1, keep=keep1),
                      _attn_problem(q1, 0, Hb, kv2, 0, 2 * Hb, kv2, Hb, 2 * Hb, mask2, R, T, p2, site2, ctx=ctx2, lse=lse2, keep=keep2),
