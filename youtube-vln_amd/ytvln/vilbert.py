@@ -113,7 +113,11 @@ def _drop_state(module: nn.Module, x: torch.Tensor) -> Optional[DropoutState]:
     if not module.training:
         return None
     if _Runtime.drop is None:
-        _Runtime.drop = DropoutState(x.device)
+        # (a module used on its own, e.g. a bare BertEncoder: no _begin_forward ran.)  Inside a two-stream region the clone of the seed and the
+        # counter increment must be ordered before BOTH sides' first read: enqueue them on the main stream and make that the new fork point,
+        # whichever side asks first (created on the side stream, the main stream could read the state before it was written).
+        with ops.TwoStream.shared_write():
+            _Runtime.drop = DropoutState(x.device)
         _share_drop_state()
     return _Runtime.drop
 
