@@ -10,16 +10,18 @@ lib = _lib.load()
 IMG = [(16128, 1024, 1024, 1), (16128, 1024, 1024, 0), (16128, 3072, 1024, 1), (16128, 1024, 3072, 0), (16128, 2048, 1024, 1), (16128, 1024, 2048, 0)]
 TEXT = [(4480, 3072, 768, 1), (4480, 768, 3072, 1), (4480, 3072, 768, 0), (4480, 768, 3072, 0), (4480, 2304, 768, 1), (4480, 768, 2304, 0),
         (4480, 768, 768, 1), (4480, 30528, 768, 1)]
+DW = [(1024, 1024, 16128, 2), (3072, 1024, 16128, 2), (2048, 1024, 16128, 2), (768, 3072, 4480, 2), (3072, 768, 4480, 2), (2304, 768, 4480, 2)]      # 2: weight-gradient layout (A = dY^T: M-contiguous, B = X [K, N])
 which = os.environ.get("SHAPES", "all")
-shapes = {"img": IMG, "text": TEXT, "all": IMG + TEXT}[which]
+shapes = {"img": IMG, "text": TEXT, "dw": DW, "all": IMG + TEXT, "all3": IMG + TEXT + DW}[which]
 ITERS = int(os.environ.get("ITERS", "20"))
 CONFIGS = [("old", dict(GEMM_SK=0)), ("dp4", dict(GEMM_SK=2, GEMM_SK_TILE=4)), ("sk4", dict(GEMM_SK=3, GEMM_SK_TILE=4)),
            ("dp3", dict(GEMM_SK=2, GEMM_SK_TILE=3)), ("sk3", dict(GEMM_SK=3, GEMM_SK_TILE=3)),
+           ("sw4", dict(GEMM_SK=0, GEMM_TILE=4, GEMM_SW=1)), ("sw3", dict(GEMM_SK=0, GEMM_TILE=3, GEMM_SW=1)), ("old3", dict(GEMM_SK=0, GEMM_TILE=3)),
            ("old4", dict(GEMM_SK=0, GEMM_TILE=4)), ("old0", dict(GEMM_SK=0, GEMM_TILE=0)), ("sk0", dict(GEMM_SK=3, GEMM_SK_TILE=0)),
            ("dp0", dict(GEMM_SK=2, GEMM_SK_TILE=0)), ("sk0g1", dict(GEMM_SK=3, GEMM_SK_TILE=0, GEMM_SK_GROUPS=1))]
 if os.environ.get("CONFIGS"):
     CONFIGS = [c for c in CONFIGS if c[0] in os.environ["CONFIGS"].split(",")]
-DEFAULTS = dict(GEMM_SK=1, GEMM_SK_TILE=-1, GEMM_SK_GROUPS=8, GEMM_TILE=-1)
+DEFAULTS = dict(GEMM_SK=0, GEMM_SK_TILE=-1, GEMM_SK_GROUPS=8, GEMM_TILE=-1, GEMM_SW=0)
 
 
 def setopts(d):
@@ -54,11 +56,14 @@ def heat(ms=400):
 
 
 for (M, N, K, tb) in shapes:
-    A = torch.randn(M, K, device=dev)
+    ta = 1 if tb == 2 else 0
+    tb = 0 if tb == 2 else tb
+    A = torch.randn((K, M) if ta else (M, K), device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     C = torch.empty(M, N, device=dev)
-    go = lambda: ops._gemm(A, K, 0, B, B.stride(0), tb, C, N, M, N, K)
-    lib_go = (lambda: torch.mm(A, B.t(), out=C)) if tb else (lambda: torch.mm(A, B, out=C))
+    go = lambda: ops._gemm(A, A.stride(0), ta, B, B.stride(0), tb, C, N, M, N, K)
+    Aop = A.t() if ta else A
+    lib_go = (lambda: torch.mm(Aop, B.t(), out=C)) if tb else (lambda: torch.mm(Aop, B, out=C))
     best = {}
     for ps in range(PASSES):          # interleaved passes, the order reversed every other pass: min over passes per configuration
         heat()
@@ -70,7 +75,7 @@ for (M, N, K, tb) in shapes:
                 setopts(o)
                 us = timed(go)
             best[name] = min(best.get(name, 1e30), us)
-    line = f"{M:6d} {N:6d} {K:5d} tB{tb} "
+    line = f"{M:6d} {N:6d} {K:5d} tA{ta} tB{tb} "
     for name, _ in CONFIGS + [("hipblaslt", None)]:
         line += f" {name} {best[name]:7.1f}us {2.0 * M * N * K / best[name] / 1e6:6.1f}TF |"
     print(line, flush=True)

@@ -449,6 +449,10 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         // (Measured and rejected, round 1: 256x128 tiles; 16-deep k-tiles with 2/3/4-stage rings (up to 4 workgroups per CU); forcing
         //  the LDS fragment reads one k-group ahead of the MFMAs.  All within +-3 % of this configuration: in the main loop the matrix
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
+        if constexpr (BM == 256) {                  // (GEMM_SW: the one-wave-per-SIMD form of the same tile, gemm_sw.hip)
+            const int sw = opt(OPT_GEMM_SW);
+            if (sw && (sw == 1 || g.splits == 1) && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
+        }
         if constexpr (BM == 256 && BN == 256) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {

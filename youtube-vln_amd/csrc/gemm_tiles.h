@@ -362,6 +362,9 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 
+// ---- one-wave-per-SIMD kernels (gemm_sw.hip): false when no instantiation exists for the tile -----------------------------------------
+bool launch_sw(int bm, int bn, const GemmArgs& g, int transA, int transB, unsigned grid, hipStream_t s);
+
 // ---- persistent / stream-K kernel (gemm_sk.hip) -------------------------------------------------------------------------------------
 struct SkPlan { int use; int tile; int dp; int G; int ngroups; double cost; };       // tile: 3 = 256x128, 4 = 256x256; cost: model estimate, us
 SkPlan plan_sk(int M, int N, int Kloop, int transA, int epilogue, bool fast, bool x3);
