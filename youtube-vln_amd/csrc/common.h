@@ -39,7 +39,7 @@ enum Option {
     OPT_GEMM_SPLITS,         // -1 (default): planner; n forces the split-K count where split-K is legal
     OPT_GEMM_SPLIT_MAP,      // 1 (default): split-K workgroups laid out split-major per XCD; 0: split-fastest (same results, more fabric traffic)
     OPT_GEMM_GENERIC,        // 1: every fp32 GEMM on the register-staged generic kernel (default 0)
-    OPT_GEMM_SW,             // one-wave-per-SIMD fp32 GEMM kernels (gemm_sw.hip) for the 256-row tiles: 0 never, 1 every such launch, 2 only launches without split-K
+    OPT_GEMM_SW,             // one-wave-per-SIMD fp32 GEMM kernels (gemm_sw.hip) for the 256-row tiles: 0 never, 1 every such launch, 2 only launches without split-K, 3 the 256x256 launches whose B operand is [K, N]
     OPT_GEMM_SK,             // persistent fp32 GEMM (gemm_sk.hip): 0 (default) never -- it measured 3-10 % behind the launch-per-tile kernel on every cfg-2 shape
                              // (profiles/round5_gemm_forms.log) --, 1 where its cost model wins, 2 whole-tile (DP) form wherever legal, 3 stream-K form wherever legal
     OPT_GEMM_SK_TILE,        // -1 (default): planner; 3 / 4 forces 256x128 / 256x256 tiles for the persistent kernel

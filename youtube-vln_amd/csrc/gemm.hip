@@ -451,7 +451,10 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
         //  cores are ~88 % busy, the rest of the gap to peak is workgroup prologue / epilogue / dispatch.  See DESIGN.md section 5.)
         if constexpr (BM == 256) {                  // (GEMM_SW: the one-wave-per-SIMD form of the same tile, gemm_sw.hip)
             const int sw = opt(OPT_GEMM_SW);
-            if (sw && (sw == 1 || g.splits == 1) && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
+            // 3: where it measured ahead -- 256x256 tiles whose B operand is [K, N] (input gradients and weight gradients: +0.5 ... +2.6 % per launch;
+            //    the forward layout, B = nn.Linear weight [N, K], measured 3 % behind and stays on the two-waves-per-SIMD kernel)
+            const bool take = sw == 1 || (sw == 2 && g.splits == 1) || (sw == 3 && BN == 256 && !transB);
+            if (take && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
         }
         if constexpr (BM == 256 && BN == 256) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
