@@ -300,11 +300,14 @@ def attn_form(request):
 
 
 _ATTN_SHAPES = [(2, 4, 8, 8, 6), (2, 4, 12, 6, 6), (3, 4, 64, 80, 80), (2, 8, 128, 288, 288), (2, 8, 128, 80, 288), (2, 8, 128, 288, 80),
-                (2, 2, 64, 16, 8), (1, 2, 128, 252, 100), (1, 3, 32, 33, 65), (1, 2, 64, 1000, 808), (1, 1, 128, 1, 3), (1, 2, 64, 512, 512)]
+                (2, 2, 64, 16, 8), (1, 2, 128, 252, 100), (1, 3, 32, 33, 65), (1, 2, 64, 1000, 808), (1, 1, 128, 1, 3), (1, 2, 64, 512, 512),
+                # query / key counts around the 32-row granule of the text stream (T = 80) and of short instructions
+                (2, 8, 128, 17, 95), (2, 8, 128, 95, 17), (2, 8, 128, 16, 80), (2, 8, 128, 80, 16), (2, 12, 64, 17, 16), (2, 12, 64, 95, 80)]
 # the one-wave dK/dV kernel directly against fp64: unpadded d = 128 / d = 64 heads, ragged query / key tiles, fully masked rows, 576 keys,
 # single tile; (29, 8, 128, 288, 288) has 2088 wave slots >= 2 rounds of 1024 and takes that kernel by the DEFAULT selection
 _W1_SHAPES = [(3, 4, 64, 80, 80), (2, 8, 128, 288, 288), (2, 8, 128, 80, 288), (2, 8, 128, 288, 80), (2, 2, 64, 16, 8), (1, 2, 128, 252, 100),
-              (2, 2, 128, 37, 101), (1, 1, 128, 1, 3), (1, 2, 64, 512, 512), (1, 2, 128, 100, 576), (2, 3, 64, 33, 288)]
+              (2, 2, 128, 37, 101), (1, 1, 128, 1, 3), (1, 2, 64, 512, 512), (1, 2, 128, 100, 576), (2, 3, 64, 33, 288),
+              (2, 8, 128, 17, 95), (2, 8, 128, 95, 17), (2, 8, 128, 16, 80), (2, 8, 128, 80, 16), (2, 12, 64, 17, 16), (2, 12, 64, 95, 80)]
 
 
 @pytest.mark.parametrize("N,heads,d,Tq,Tk,attn_form",

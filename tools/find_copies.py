@@ -25,7 +25,7 @@ for s in range(3):
     utils_init.train_step(model, opt, sched, batch, args, s, all_options=True)
 torch.cuda.synchronize()
 STEPS = 2
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     for s in range(STEPS):
         utils_init.train_step(model, opt, sched, batch, args, 3 + s, all_options=True)
     torch.cuda.synchronize()
@@ -38,7 +38,8 @@ for ev in prof.events():
     if ev.device_type != torch.autograd.DeviceType.CPU:
         continue
     st = [f for f in (ev.stack or []) if "ytvln" in f or "bench.py" in f]
-    where = st[0].strip() if st else "(no ytvln frame)"
-    cnt[(n, where[-110:])] += 1
-for (n, w), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:45]:
+    where = st[0].strip()[-80:] if st else ""
+    shapes = str([tuple(x) if isinstance(x, (list, tuple)) else x for x in (ev.input_shapes or [])])[:90]
+    cnt[(n, shapes + " " + where)] += 1
+for (n, w), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:70]:
     print(f"{c / STEPS:7.1f}/step  {n:22s} {w}")
