@@ -69,7 +69,7 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.ytvln_gemm_workspace_elems(1024, 1024, 16128, 0) > 0
     assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) == 2 * 256 * 256 * 256      # two banks of one partial tile per workgroup of a stream-K launch
     assert lib.ytvln_gemm_workspace_elems(100, 64, 64, 0) == 0
-    assert lib.ytvln_ln_bwd_blocks(16128) == 1008
+    assert lib.ytvln_ln_bwd_blocks(16128) == 768
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

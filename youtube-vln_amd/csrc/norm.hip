@@ -193,8 +193,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     }
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(r0 + a.rows_per_block, a.rows);
+    // A wave walks its rows with the loads of the NEXT row issued in front of the arithmetic, the two wave reductions and the stores of the
+    // current one (the stores may alias the loads as far as the compiler knows, so it keeps them in program order: without the explicit
+    // prefetch a wave has one row of loads in flight, waits, reduces, stores, and only then asks for the next row).
+    float4 dn[NV], sn[NV];
+    float mun = 0.f, rsn = 0.f;
+    auto fetch = [&](int64_t row) __attribute__((always_inline)) {
+        mun = a.mean[row]; rsn = a.rstd[row];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 < H4) { dn[j] = ld4(dyin + row * a.H, c4); sn[j] = ld4(sin + row * a.H, c4); }
+        }
+    };
+    if (r0 + wave < r1) fetch(r0 + wave);
     for (int64_t row = r0 + wave; row < r1; row += 4) {
-        const float mu = a.mean[row], rs = a.rstd[row];
+        const float mu = mun, rs = rsn;
+        float4 dc[NV], sc[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { dc[j] = dn[j]; sc[j] = sn[j]; }
+        if (row + 4 < r1) fetch(row + 4);
         float4 g[NV], xh[NV];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -202,9 +220,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
             const int c4 = lane + 64 * j;
             g[j] = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = g[j];
             if (c4 < H4) {
-                float4 d = ld4(dyin + row * a.H, c4);
+                float4 d = dc[j];
                 if (post) d = drop4(d, key, (uint64_t)row, H4, c4, x8, thr_post, ik_post);
-                const float4 sv = ld4(sin + row * a.H, c4);
+                const float4 sv = sc[j];
                 xh[j] = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
                 dg[j].x += d.x * xh[j].x; dg[j].y += d.y * xh[j].y; dg[j].z += d.z * xh[j].z; dg[j].w += d.w * xh[j].w;
                 db[j] = f4add(db[j], d);
@@ -687,7 +705,9 @@ extern "C" int ytvln_image_embed_fwd_f32(const float* img, const float* loc, con
     return 0;
 }
 
-extern "C" int ytvln_ln_bwd_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, cdiv(rows, 16))); }
+// (768 = three 4-wave workgroups per CU, what the H = 1024 kernel's registers allow: 1008 sixteen-row blocks ran as one full round plus a
+//  third of one at a quarter of the occupancy)
+extern "C" int ytvln_ln_bwd_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(768, cdiv(rows, 16))); }
 
 extern "C" int ytvln_ln_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                                 float* ds, float* dx, float* partial, int64_t rows, int H, float p_pre, float p_post,
