@@ -2,7 +2,7 @@
 # LayerNorm backward with next-row prefetch and 768 blocks against the committed kernel: tests, micro-benchmark, headline ABAB
 mkdir -p gpurun_out; export TMPDIR=/tmp
 BASE=$PWD/youtube-vln_amd/ytvln/lib/libytvln_base.so
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bf16_gpu.py -m gpu -x -q -k "layernorm or ln or embed" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bf16_gpu.py -m gpu -x -q -k "layernorm or ln or embed or linear or g0 or g2" 2>&1 | tail -3
 for v in base new base new; do
 if [ $v = base ]; then export YTVLN_LIB=$BASE; else unset YTVLN_LIB; fi
 echo "== $v"; timeout 300 python tools/ln_bench.py 2>&1 | grep -v amdgpu.ids

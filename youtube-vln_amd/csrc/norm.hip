@@ -706,8 +706,8 @@ extern "C" int ytvln_image_embed_fwd_f32(const float* img, const float* loc, con
 }
 
 // (768 = three 4-wave workgroups per CU, what the H = 1024 kernel's registers allow: 1008 sixteen-row blocks ran as one full round plus a
-//  third of one at a quarter of the occupancy)
-extern "C" int ytvln_ln_bwd_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(768, cdiv(rows, 16))); }
+//  third of one at a quarter of the occupancy; the 4480-row text launches had 280 blocks = four waves per CU)
+extern "C" int ytvln_ln_bwd_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(768, cdiv(rows, 4))); }
 
 extern "C" int ytvln_ln_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma,
                                 float* ds, float* dx, float* partial, int64_t rows, int H, float p_pre, float p_post,
