@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 // mask from ONE Philox call per 8 elements (16 bits per element: keep iff bits16 >= round(p * 65536); P(drop) = 0.1000061 for p = 0.1).
 // Forward and backward regenerate the same mask from (seed, counter, site, row, vector index); the fp32 kernels keep their 32-bit draws.
 struct f8 { float v[8]; };
-__device__ __forceinline__ f8 ld8(const bf16_t* p, int64_t c8) {
-    const uint4 u = reinterpret_cast<const uint4*>(p)[c8];
+__device__ __forceinline__ uint4 ld8raw(const bf16_t* p, int64_t c8) { return reinterpret_cast<const uint4*>(p)[c8]; }
+__device__ __forceinline__ f8 cvt8(const uint4 u) {
     f8 r;
     r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
     r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
@@ -276,6 +276,7 @@ __device__ __forceinline__ f8 ld8(const bf16_t* p, int64_t c8) {
     r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
     return r;
 }
+__device__ __forceinline__ f8 ld8(const bf16_t* p, int64_t c8) { return cvt8(ld8raw(p, c8)); }
 __device__ __forceinline__ void st8(bf16_t* p, int64_t c8, const f8& r) {
     reinterpret_cast<uint4*>(p)[c8] = make_uint4(bfbits(r.v[0]) | (bfbits(r.v[1]) << 16), bfbits(r.v[2]) | (bfbits(r.v[3]) << 16),
                                                  bfbits(r.v[4]) | (bfbits(r.v[5]) << 16), bfbits(r.v[6]) | (bfbits(r.v[7]) << 16));
@@ -317,17 +318,35 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const LnArgs a) {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
         if (lane + 64 * j < H8) { gm[j] = ldg8(a.gamma, lane + 64 * j); bt[j] = ldg8(a.beta, lane + 64 * j); }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+    // next row's loads in front of this row's reductions and stores (see ln_bwd_kernel)
+    uint4 xn[NV], rn[NV];
+    const int64_t rstep = (int64_t)gridDim.x * 4;
+    auto fetch = [&](int64_t row) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c8 = lane + 64 * j;
+            if (c8 < H8) {
+                xn[j] = ld8raw(xin + row * a.H, c8);
+                if (rin) rn[j] = ld8raw(rin + row * a.H, c8);
+            }
+        }
+    };
+    if ((int64_t)blockIdx.x * 4 + wave < a.rows) fetch((int64_t)blockIdx.x * 4 + wave);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += rstep) {
+        uint4 xc[NV], rc[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { xc[j] = xn[j]; rc[j] = rn[j]; }
+        if (row + rstep < a.rows) fetch(row + rstep);
         f8 s[NV];
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c8 = lane + 64 * j;
             if (c8 < H8) {
-                s[j] = ld8(xin + row * a.H, c8);
+                s[j] = cvt8(xc[j]);
                 if (pre) keep8(s[j], drop_bits(key, (uint64_t)row * H8 + c8), thr_pre, ik_pre);
                 if (rin) {
-                    const f8 r = ld8(rin + row * a.H, c8);
+                    const f8 r = cvt8(rc[j]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) s[j].v[e] += r.v[e];
                 }
@@ -392,17 +411,33 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const LnBwdArgs a) {
     }
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(r0 + a.rows_per_block, a.rows);
+    // next row's loads in front of this row's reductions and stores (see ln_bwd_kernel)
+    uint4 dn[NV], sn[NV];
+    float mun = 0.f, rsn = 0.f;
+    auto fetch = [&](int64_t row) __attribute__((always_inline)) {
+        mun = a.mean[row]; rsn = a.rstd[row];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c8 = lane + 64 * j;
+            if (c8 < H8) { dn[j] = ld8raw(dyin + row * a.H, c8); sn[j] = ld8raw(sin + row * a.H, c8); }
+        }
+    };
+    if (r0 + wave < r1) fetch(r0 + wave);
     for (int64_t row = r0 + wave; row < r1; row += 4) {
-        const float mu = a.mean[row], rs = a.rstd[row];
+        const float mu = mun, rs = rsn;
+        uint4 dc[NV], sc[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { dc[j] = dn[j]; sc[j] = sn[j]; }
+        if (row + 4 < r1) fetch(row + 4);
         f8 g[NV], xh[NV];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c8 = lane + 64 * j;
             if (c8 < H8) {
-                f8 d = ld8(dyin + row * a.H, c8);
+                f8 d = cvt8(dc[j]);
                 if (post) keep8(d, drop_bits(key, (uint64_t)row * H8 + c8), thr_post, ik_post);
-                const f8 sv = ld8(sin + row * a.H, c8);
+                const f8 sv = cvt8(sc[j]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     xh[j].v[e] = (sv.v[e] - mu) * rs;
@@ -832,7 +867,7 @@ extern "C" int ytvln_ln_fwd_bf16(const uint16_t* x, const uint16_t* res, const f
     a.rows = rows; a.H = H; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.rng = rng; a.site = site;
     if (H % 8 == 0 && al16(x) && al16(y) && (!res || al16(res)) && (!s_out || al16(s_out))) {          // 16 bytes per lane
         const int nv = (int)cdiv(H / 8, 64);
-        const int grid = (int)std::min<int64_t>(cdiv(rows, 4), 8192);
+        const int grid = (int)std::min<int64_t>(cdiv(rows, 4), nv <= 2 ? 1024 : 512);          // one resident round; the waves walk rows with a prefetch
         hipStream_t st = as_stream(stream);
         if (nv <= 1) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<1>), dim3(grid), dim3(256), 0, st, a);
         else if (nv <= 2) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<2>), dim3(grid), dim3(256), 0, st, a);
