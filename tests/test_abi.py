@@ -111,6 +111,9 @@ def test_gemm_launch_planner_host_logic():
     assert plan(16128, 1024, 1024) == (256, 256, 1)            # image-stream projection: one wave of 252 big tiles
     assert plan(24192, 1024, 1024)[:2] != (256, 256)           # config 4: 95 x 4 = 380 tiles of 256x256 would leave half a wave idle
     assert plan(4480, 768, 3072) == (128, 128, 1)              # 210 tiles: one wave, no split-K round trip
+    assert plan(4480, 3072, 768) == (224, 256, 1)              # 4480 = 20 x 224: 240 whole tiles in one round (216 of 256x256, 12 of them half empty)
+    assert plan(4480, 2304, 768) == (160, 256, 1)              # 4480 = 28 x 160: 252 whole tiles in one round
+    assert plan(4480, 30528, 768)[0] != 224                    # many rounds: no gain from the 224-row tile (measured), stays on the well-trodden ones
     assert plan(4480, 1024, 768)[:2] == (64, 64)               # 280 128x128 tiles = 55 % of two waves -> small tiles
     # weight gradients (M-contiguous A): few tiles, long contraction -> deterministic split-K; since round 2 the 256x256 tile competes there
     # (half the operand bytes per flop) and wins when tiles x splits fills one round of the 256 CUs

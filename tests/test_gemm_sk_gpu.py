@@ -150,3 +150,50 @@ def test_persistent_gemm_two_streams_at_once(dev, lib):
         torch.cuda.synchronize()
     assert all(torch.equal(c, C_ref) for c in Cs) and all(torch.equal(d, D_ref) for d in Ds)
     assert _ctl_zero(dev)
+
+
+@pytest.mark.parametrize("M,N,K,tb,epi", [(4480, 3072, 768, 1, 1), (4480, 3072, 768, 0, 3), (4480, 30528, 768, 1, 0), (4480, 768, 3072, 1, 0),
+                                          (4480, 2304, 768, 1, 0), (4500, 1032, 160, 0, 2), (16128, 1024, 1024, 1, 0), (300, 520, 96, 1, 0)])
+@pytest.mark.parametrize("tile,bm", [(5, 224), (6, 160)])
+def test_gemm_224_row_tile_every_tile_right(dev, lib, M, N, K, tb, epi, tile, bm):
+    """The 224x256 / 160x256 tiles of gemm_dma_kernel (eight waves of 224x32 / 160x32; 28 / 20 LDS-DMA pieces of A over 8 waves: the last waves own fewer): every
+    128x128 output tile against fp64, ragged M / N (boundary epilogue, clamped DMA rows), fused epilogues, bit-reproducible, and -- the k order
+    per accumulator being the same -- bit-identical to the 256x256 tile."""
+    from ytvln import ops
+    A = _rand(dev, M, K, seed=M + K)
+    B = _rand(dev, *((N, K) if tb else (K, N)), seed=N + 7 * K)
+    bias = None if epi == 3 else _rand(dev, N, seed=3)
+    aux_in = _rand(dev, M, N, seed=11) if epi == 3 else None
+    ref = A.double() @ (B.double().t() if tb else B.double())
+    if bias is not None:
+        ref = ref + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = ref.clamp(min=0)
+    elif epi == 3:
+        z = aux_in.double()
+        ref = ref * (0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * math.pi) ** 0.5)
+
+    def run(**opts):
+        C = torch.full((M, N), float("nan"), device=dev)
+        aux = aux_in.clone() if epi == 3 else (torch.empty(M, N, device=dev) if epi == 1 else None)
+        with _Opts(**opts):
+            ops._gemm(A, K, 0, B, B.stride(0), tb, C, N, M, N, K, bias=bias, aux=aux, ldaux=N, epi=epi)
+        torch.cuda.synchronize()
+        return C
+
+    import ctypes
+    tm, tn, sp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    with _Opts(GEMM_T224=1, GEMM_TILE=tile, GEMM_SK=0):
+        lib.ytvln_gemm_plan(M, N, K, 0, epi, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp))
+    assert (tm.value, tn.value, sp.value) == (bm, 256, 1)
+    C = run(GEMM_T224=1, GEMM_TILE=tile, GEMM_SK=0)
+    assert torch.isfinite(C).all(), "a tile was never written"
+    err = _tile_errors(C, ref)
+    bar = 4e-6 * math.sqrt(K) + 1e-6
+    assert float(err.max()) < bar, (float(err.max()), bar, torch.nonzero(err >= bar)[:8].tolist())
+    for _ in range(5):
+        assert torch.equal(C, run(GEMM_T224=1, GEMM_TILE=tile, GEMM_SK=0))
+    C4 = run(GEMM_TILE=4, GEMM_SPLITS=1, GEMM_SK=0)
+    assert torch.equal(C, C4), float((C - C4).abs().max())

@@ -44,6 +44,7 @@ enum Option {
                              // (profiles/round5_gemm_forms.log) --, 1 where its cost model wins, 2 whole-tile (DP) form wherever legal, 3 stream-K form wherever legal
     OPT_GEMM_SK_TILE,        // -1 (default): planner; 3 / 4 forces 256x128 / 256x256 tiles for the persistent kernel
     OPT_GEMM_SK_GROUPS,      // 8 (default): one ticket group per XCD; 1: one group over the whole launch (partial tiles may cross XCDs)
+    OPT_GEMM_T224,           // 1 (default): the fp32 planner may take the 224x256 tile (eight waves of 224x32) for single-round launches with a K-contiguous A; 0: never
     OPT_COUNT
 };
 int opt(int id);

@@ -128,12 +128,13 @@ __device__ __forceinline__ Split3 split3(const float4 u, const float4 v) {
     return s;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool X3 = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool X3 = false, int WN = 2>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g) {
     using TA = DmaTile<BM, A_KC, NW, KB>;
     using TB = DmaTile<BN, B_KC, NW, KB>;
-    constexpr int WM = NW / 2;                         // waves along m (x 2 along n)
-    constexpr int TM = BM / WM / 32, TN = BN / 64;
+    constexpr int WM = NW / WN;                        // waves along m x WN along n (2, or 8 for the 224-row tile: eight waves of 224x32)
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "wave grid does not cover the tile");
     constexpr int SA = BM * KB, SB = BN * KB, STAGE = SA + SB;
     constexpr int NPT = TA::NI + TB::NI;               // DMA instructions per wave per k-tile
     constexpr int NG = KB / 8;                         // 4-deep k-groups per half-wave per k-tile
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave >> 1) * (BM / WM), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const TileCoord tc = decode_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.splits, g.split_map);
     const int m0 = tc.m * BM, n0 = tc.n * BN;
     const int kbeg = tc.split * g.kchunk;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
 
     // Row sums of op(A) over this workgroup's k range (db = sum over rows of dY, riding on dW = dY^T X): every tile column reads the same
     // A panel, so the workgroups of tile column 0 (and there the waves of wave column 0) add up the fragments they feed to the MFMAs.
-    const bool do_asum = !A_KC && !X3 && g.asum != nullptr && tc.n == 0 && (wave & 1) == 0;
+    const bool do_asum = !A_KC && !X3 && g.asum != nullptr && tc.n == 0 && (wave % WN) == 0;
     float asum[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
@@ -185,12 +186,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         }
 #pragma unroll
         for (int i = 0; i < TA::NI; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
+            if (TA::own(wave, i)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
             pa[i] += sa;
         }
 #pragma unroll
         for (int i = 0; i < TB::NI; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
+            if (TB::own(wave, i)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
             pb[i] += sb;
         }
     };
@@ -364,23 +365,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //     per tile, the last workgroup to arrive adds them in split order.  Bit-identical to the separate pass, but one workgroup per output
 //     tile moves splits x tile bytes at a latency-bound ~50 GB/s while the separate pass uses the whole chip: 119.3 -> 119.7 ms per step
 //     when applied to launches with <= 4 splits, 122.4 with <= 8, 126.2 with all.  profiles/round3_fused_splitk.log.)
-struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256 (one workgroup per CU)
+struct Plan { int tile; int splits; };      // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128, 4 = 256x256, 5 = 224x256, 6 = 160x256 (3-6: one workgroup per CU)
 
 static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0, bool x3 = false, bool ta = false) {
     // the two large tiles move fewer operand bytes and LDS fragments per MFMA: ~3 % / ~7 % above the 128x128 rate per CU
-    static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
+    static const int bm[7] = {128, 128, 64, 256, 256, 224, 160}, bn[7] = {128, 64, 64, 128, 256, 256, 256};
     // us per 32-deep k-tile at the CU-exclusive rate: native fp32 MFMA | three-bf16-term form (fitted on 16128x1024x1024: the split's
     // VALU work is shared best by the wide wave tiles -- 128x128 is VALU-bound, 256x256 matrix-bound)
     // (64x64 and 256x128 exist only for the native instruction: the three-term planner sees their native cost)
     // Round 5: refitted after the interior epilogue stopped spilling (gemm_tiles.h epilogue_interior): the 256x256 tile's fixed cost fell from
     // 25 to ~10 us (ramp + first operands ~4, epilogue 4.5, drain) and its k-tile measures 7.5 us in whole-chip launches (16128x{1024,2048,3072}x1024:
     // 251.8 / 497.8 / 744.3 us = 1 / 2 / 3 rounds of ~249); 128x128: 2.06 us per k-tile, ~1 us fixed (266 / 784 / 1612 us on 4 / 12 / 33 rounds).
-    static const double tk_f32[5] = {2.06, 1.14, 0.55, 4.4, 7.5}, tk_x3[5] = {1.61, 0.82, 0.55, 4.16, 4.94};
-    static const double tfix[5] = {1.0, 3.0, 3.0, 6.0, 10.0};
+    // 224x256 (eight waves of 224x32: seven 32x32 blocks each): 7/8 of the 256x256 k-tile; it exists for the 4480-row text shapes
+    // (4480 = 20 x 224: 240 whole tiles at N = 3072 instead of 216 of which 12 are half empty)
+    // and 160x256 (five blocks per wave; 4480 = 28 x 160: 252 whole tiles at N = 2304)
+    static const double tk_f32[7] = {2.06, 1.14, 0.55, 4.4, 7.5, 6.6, 4.75}, tk_x3[7] = {1.61, 0.82, 0.55, 4.16, 4.94, 4.94, 4.94};
+    static const double tfix[7] = {1.0, 3.0, 3.0, 6.0, 10.0, 10.0, 9.0};
     // native instruction, M-contiguous A (the weight-gradient layout: both operands k-major, fragments gathered by ds_read_b32): fitted in
     // round 2 on the cfg-2 weight-gradient shapes (tools/r2_gpu37.sh) -- the 128x128 workgroups run at 2.3 us per k-tile there (half the
     // flops per operand byte: ~3.7 TB/s of LDS-DMA at 120 TFLOP/s, the same delivery ceiling the fp32x3 256x256 kernel meets), the 256x256 at 7.3
-    static const double tk_f32_ta[5] = {2.3, 1.14, 0.55, 4.16, 7.3};
+    static const double tk_f32_ta[7] = {2.3, 1.14, 0.55, 4.16, 7.3, 7.3, 7.3};
     const double* tk = x3 ? tk_x3 : (ta ? tk_f32_ta : tk_f32);
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
     const int splits = (int)cdiv(K, kchunk);
@@ -405,9 +409,12 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
     Plan best = {0, 1};
     double best_t = 1e30;
     const int force_tile = opt(OPT_GEMM_TILE), force_sp = opt(OPT_GEMM_SPLITS);       // experiment knobs (-1: the planner decides)
-    for (int tile = 0; tile < 5; ++tile) {
+    for (int tile = 0; tile < 7; ++tile) {
         if (force_tile >= 0 && tile != force_tile) continue;
         if (tile >= 3 && (!big_ok || M < 256)) continue;
+        // 224x256: native instruction, K-contiguous A, launches of ONE round (measured: 4480x3072x768 189.7 -> 170.5 us; the 2400-tile LM decoder
+        // gains nothing over 2160 tiles of 256x256 -- multi-round launches already overlap their tiles' fixed costs)
+        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && cdiv(M, tile == 5 ? 224 : 160) * cdiv(N, 256) > 256))) continue;
         if (ta && tile == 3) continue;          // (256x128 was never measured with an M-contiguous A)
         // split-K: 128x128 always; 256x256 in the three-term form and -- round 2 -- for the native weight-gradient layout (ta):
         // 1024x1024x16128 323 -> 305 us, 2048x1024x16128 551 -> 505, 768x3072x4480 190 -> 178 (16 x 16, 32 x 8, 36 x 7 workgroups)
@@ -456,7 +463,11 @@ static int launch_tile(GemmArgs& g, int transA, int transB, hipStream_t s) {
             const bool take = sw == 1 || (sw == 2 && g.splits == 1) || (sw == 3 && BN == 256 && !transB);
             if (take && !g.x3 && launch_sw(BM, BN, g, transA, transB, grid.x, s)) return 0;
         }
-        if constexpr (BM == 256 && BN == 256) {
+        if constexpr (BM == 224 || BM == 160) {     // 8 waves of BM x 32 (K-contiguous A only: plan_gemm)
+            dim3 blk(512);
+            if (transB) hipLaunchKernelGGL((gemm_dma_kernel<BM, 256, true, true, 8, 32, 2, 2, false, 8>), grid, blk, 0, s, g);
+            else hipLaunchKernelGGL((gemm_dma_kernel<BM, 256, true, false, 8, 32, 2, 2, false, 8>), grid, blk, 0, s, g);
+        } else if constexpr (BM == 256 && BN == 256) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x128, one workgroup per CU
         } else if constexpr (BM == 256 && BN == 128) {
             YT_DMA(8, 32, 2, 2);                    // 8 waves of 64x64, one workgroup per CU (native instruction only, like 64x64)
@@ -484,7 +495,7 @@ using namespace ytvln;
 
 extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
     YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan: bad argument");
-    static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
+    static const int bm[7] = {128, 128, 64, 256, 256, 224, 160}, bn[7] = {128, 64, 64, 128, 256, 256, 256};
     const Plan p = plan_gemm(M, N, K, epilogue, true, false, transA != 0);
     *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
     return 0;
@@ -493,7 +504,7 @@ extern "C" int ytvln_gemm_plan(int M, int N, int K, int transA, int epilogue, in
 extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue, int* tile_m, int* tile_n, int* splits) {
     YT_REQUIRE(tile_m && tile_n && splits && M > 0 && N > 0 && K > 0, "gemm_plan_x3: bad argument");
     (void)transA;       // the three-term form takes the 256-row tiles with either A layout (see ytvln_gemm_f32)
-    static const int bm[5] = {128, 128, 64, 256, 256}, bn[5] = {128, 64, 64, 128, 256};
+    static const int bm[7] = {128, 128, 64, 256, 256, 224, 160}, bn[7] = {128, 64, 64, 128, 256, 256, 256};
     const Plan p = plan_gemm(M, N, K, epilogue, true, true);
     *tile_m = bm[p.tile]; *tile_n = bn[p.tile]; *splits = p.splits;
     return 0;
@@ -590,6 +601,9 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     } else {
         g.splits = 1;
         if (plan.tile == 4) launch_tile<256, 256>(g, transA, transB, s);
+        else if (plan.tile == 5 && g.fast && !transA && !g.x3) launch_tile<224, 256>(g, transA, transB, s);
+        else if (plan.tile == 6 && g.fast && !transA && !g.x3) launch_tile<160, 256>(g, transA, transB, s);
+        else if (plan.tile >= 5) launch_tile<256, 256>(g, transA, transB, s);
         else if (plan.tile == 3) launch_tile<256, 128>(g, transA, transB, s);
         else if (plan.tile == 0) launch_tile<128, 128>(g, transA, transB, s);
         else if (plan.tile == 1) launch_tile<128, 64>(g, transA, transB, s);

@@ -319,7 +319,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <int BMN, bool KC, int NW, int KB>
 struct DmaTile {
-    static constexpr int NI = BMN * KB / 256 / NW;  // 1 KiB pieces per wave per k-tile (BMN*KB/256 pieces, NW waves)
+    static constexpr int PIECES = BMN * KB / 256;   // 1 KiB pieces per k-tile
+    static constexpr int NI = (PIECES + NW - 1) / NW;   // pieces per wave (wave w owns pieces w*NI .. w*NI+NI-1)
+    static constexpr bool RAGGED = PIECES % NW != 0;    // 224-row tile: 28 pieces over 8 waves -- the last wave(s) own fewer; callers test `own`
+    __device__ static __forceinline__ bool own(int wave, int i) { return !RAGGED || wave * NI + i < PIECES; }
     static constexpr int GR = KB / 4;               // 16-byte granules per row of a K-contiguous image (8 or 4)
     static constexpr int RP = 256 / KB;             // rows per 1 KiB piece of a K-contiguous image (8 or 16)
     static_assert(NI >= 1 && (KB == 64 || KB == 32 || KB == 16), "unsupported DMA tile");
