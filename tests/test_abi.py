@@ -110,7 +110,7 @@ def test_gemm_launch_planner_host_logic():
 
     assert plan(16128, 1024, 1024) == (256, 256, 1)            # image-stream projection: one wave of 252 big tiles
     assert plan(24192, 1024, 1024)[:2] != (256, 256)           # config 4: 95 x 4 = 380 tiles of 256x256 would leave half a wave idle
-    assert plan(4480, 768, 3072) == (128, 128, 1)              # 210 tiles: one wave, no split-K round trip
+    assert plan(4480, 768, 3072) == (160, 256, 3)              # 84 tiles of 160x256 x 3 splits = 252 workgroups in one round (128x128 unsplit until round 5)
     assert plan(4480, 3072, 768) == (224, 256, 1)              # 4480 = 20 x 224: 240 whole tiles in one round (216 of 256x256, 12 of them half empty)
     assert plan(4480, 2304, 768) == (160, 256, 1)              # 4480 = 28 x 160: 252 whole tiles in one round
     assert plan(4480, 30528, 768)[0] != 224                    # many rounds: no gain from the 224-row tile (measured), stays on the well-trodden ones

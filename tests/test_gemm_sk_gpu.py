@@ -185,15 +185,45 @@ def test_gemm_224_row_tile_every_tile_right(dev, lib, M, N, K, tb, epi, tile, bm
 
     import ctypes
     tm, tn, sp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    with _Opts(GEMM_T224=1, GEMM_TILE=tile, GEMM_SK=0):
+    with _Opts(GEMM_T224=1, GEMM_TILE=tile, GEMM_SPLITS=1, GEMM_SK=0):
         lib.ytvln_gemm_plan(M, N, K, 0, epi, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp))
     assert (tm.value, tn.value, sp.value) == (bm, 256, 1)
-    C = run(GEMM_T224=1, GEMM_TILE=tile, GEMM_SK=0)
+    C = run(GEMM_T224=1, GEMM_TILE=tile, GEMM_SPLITS=1, GEMM_SK=0)
     assert torch.isfinite(C).all(), "a tile was never written"
     err = _tile_errors(C, ref)
     bar = 4e-6 * math.sqrt(K) + 1e-6
     assert float(err.max()) < bar, (float(err.max()), bar, torch.nonzero(err >= bar)[:8].tolist())
     for _ in range(5):
-        assert torch.equal(C, run(GEMM_T224=1, GEMM_TILE=tile, GEMM_SK=0))
+        assert torch.equal(C, run(GEMM_T224=1, GEMM_TILE=tile, GEMM_SPLITS=1, GEMM_SK=0))
     C4 = run(GEMM_TILE=4, GEMM_SPLITS=1, GEMM_SK=0)
     assert torch.equal(C, C4), float((C - C4).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(4480, 768, 3072, 1), (4480, 768, 3072, 0), (8960, 768, 3072, 1), (4480, 768, 2304, 0)])
+def test_gemm_small_row_tiles_split_k(dev, lib, M, N, K, tb):
+    """Split-K on the 160- / 224-row tiles (the planner's choice for the N = 768 text shapes: 84 tiles x 3 splits in one round): every 128x128
+    output tile against fp64, bias applied once by the fixed-order reduce, the same bits every launch."""
+    from ytvln import ops
+    import ctypes
+    A = _rand(dev, M, K, seed=M + K)
+    B = _rand(dev, *((N, K) if tb else (K, N)), seed=N + 7 * K)
+    bias = _rand(dev, N, seed=3)
+    ref = A.double() @ (B.double().t() if tb else B.double()) + bias.double()
+    tm, tn, sp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    lib.ytvln_gemm_plan(M, N, K, 0, 0, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp))
+    forced = {} if (tm.value in (160, 224) and sp.value > 1) else dict(GEMM_TILE=6, GEMM_SPLITS=3)
+
+    def run():
+        C = torch.full((M, N), float("nan"), device=dev)
+        with _Opts(GEMM_SK=0, **forced):
+            ops._gemm(A, K, 0, B, B.stride(0), tb, C, N, M, N, K, bias=bias)
+        torch.cuda.synchronize()
+        return C
+
+    C = run()
+    assert torch.isfinite(C).all()
+    err = _tile_errors(C, ref)
+    bar = 4e-6 * math.sqrt(K) + 1e-6
+    assert float(err.max()) < bar, (float(err.max()), bar, torch.nonzero(err >= bar)[:8].tolist())
+    for _ in range(5):
+        assert torch.equal(C, run())

@@ -11,8 +11,10 @@ IMG = [(16128, 1024, 1024, 1), (16128, 1024, 1024, 0), (16128, 3072, 1024, 1), (
 TEXT = [(4480, 3072, 768, 1), (4480, 768, 3072, 1), (4480, 3072, 768, 0), (4480, 768, 3072, 0), (4480, 2304, 768, 1), (4480, 768, 2304, 0),
         (4480, 768, 768, 1), (4480, 30528, 768, 1)]
 DW = [(1024, 1024, 16128, 2), (3072, 1024, 16128, 2), (2048, 1024, 16128, 2), (768, 3072, 4480, 2), (3072, 768, 4480, 2), (2304, 768, 4480, 2)]      # 2: weight-gradient layout (A = dY^T: M-contiguous, B = X [K, N])
+CO = [(4480, 768, 2048, 0), (4480, 2048, 768, 1), (4480, 1024, 768, 1), (4480, 1024, 768, 0), (4480, 768, 1024, 1), (4480, 768, 1024, 0),
+      (4480, 768, 768, 0), (16128, 1601, 1024, 1), (16128, 1024, 1601, 0)]      # co-attention text side, the 1601-way image head
 which = os.environ.get("SHAPES", "all")
-shapes = {"img": IMG, "text": TEXT, "dw": DW, "all": IMG + TEXT, "all3": IMG + TEXT + DW}[which]
+shapes = {"img": IMG, "text": TEXT, "dw": DW, "co": CO, "textco": TEXT + CO, "all": IMG + TEXT, "all3": IMG + TEXT + DW}[which]
 ITERS = int(os.environ.get("ITERS", "20"))
 CONFIGS = [("old", dict(GEMM_SK=0)), ("dp4", dict(GEMM_SK=2, GEMM_SK_TILE=4)), ("sk4", dict(GEMM_SK=3, GEMM_SK_TILE=4)),
            ("dp3", dict(GEMM_SK=2, GEMM_SK_TILE=3)), ("sk3", dict(GEMM_SK=3, GEMM_SK_TILE=3)),

@@ -399,7 +399,8 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     double t = waves * (tf + (double)(kchunk / BK) * tk[tile] * occ);
     // us: reduce launch + workspace bytes at ~3 TB/s (fitted on the native plans; the three-term plans were fitted with 5 TB/s: their
     // partials are consumed sooner and mostly hit the memory-side cache)
-    if (splits > 1) t += 8.0 + (double)(splits + 1) * (double)M * (double)N * 4.0 / (x3 ? 5.0e6 : 3.0e6);
+    // (the 160- / 224-row plans split 2-4 ways over a few MB: measured 10 us on 4480x768x3072 x 3 -- the partials never leave the memory-side cache)
+    if (splits > 1) t += (tile >= 5 ? 4.0 : 8.0) + (double)(splits + 1) * (double)M * (double)N * 4.0 / (x3 ? 5.0e6 : tile >= 5 ? 8.0e6 : 3.0e6);
     return t;
 }
 
@@ -414,13 +415,17 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         if (tile >= 3 && (!big_ok || M < 256)) continue;
         // 224x256: native instruction, K-contiguous A, launches of ONE round (measured: 4480x3072x768 189.7 -> 170.5 us; the 2400-tile LM decoder
         // gains nothing over 2160 tiles of 256x256 -- multi-round launches already overlap their tiles' fixed costs)
-        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && cdiv(M, tile == 5 ? 224 : 160) * cdiv(N, 256) > 256))) continue;
+        const int64_t ntile = tile >= 5 ? cdiv(M, tile == 5 ? 224 : 160) * cdiv(N, 256) : 0;
+        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && ntile > 256))) continue;
         if (ta && tile == 3) continue;          // (256x128 was never measured with an M-contiguous A)
         // split-K: 128x128 always; 256x256 in the three-term form and -- round 2 -- for the native weight-gradient layout (ta):
         // 1024x1024x16128 323 -> 305 us, 2048x1024x16128 551 -> 505, 768x3072x4480 190 -> 178 (16 x 16, 32 x 8, 36 x 7 workgroups)
-        const int smax = ((tile == 0 || (tile == 4 && (x3 || ta))) && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
+        // (round 5: the 224- / 160-row tiles too, as long as tiles x splits stays one round -- 4480x768x3072: 84 tiles of 160x256 x 3 splits)
+        const int smax = ((tile == 0 || tile >= 5 || (tile == 4 && (x3 || ta))) && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
+            // (long contractions: not measured, left on the old plans; short ones lose: 4480x1024x768 x 3 splits of 256 measured 76 us against 72.5)
+            if (tile >= 5 && sp > 1 && force_tile < 0 && (ntile * sp > 256 || K > 4096 || K / sp < 512)) break;
             const double t = plan_cost(M, N, K, tile, sp, epilogue, x3, ta);
             // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
             if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp}; }
@@ -511,7 +516,8 @@ extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue,
 }
 
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
-    const int splits = std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, true).splits),
+    const int splits = std::max(std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, false).splits),
+                                                  plan_gemm(M, N, K, epilogue, true, false, true).splits),
                                          std::max(plan_gemm(M, N, K, epilogue, false, true).splits,
                                                   plan_gemm(M, N, K, epilogue, true, true).splits)),
                                 1);
@@ -594,6 +600,8 @@ static int gemm_f32_impl(const float* A, int64_t lda, int transA, const float* B
     if (rowsum_done) *rowsum_done = g.asum != nullptr;
     if (g.splits > 1) {
         if (plan.tile == 4) launch_tile<256, 256>(g, transA, transB, s);
+        else if (plan.tile == 5 && g.fast && !transA && !g.x3) launch_tile<224, 256>(g, transA, transB, s);
+        else if (plan.tile == 6 && g.fast && !transA && !g.x3) launch_tile<160, 256>(g, transA, transB, s);
         else launch_tile<128, 128>(g, transA, transB, s);
         const int64_t total = (int64_t)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 2048)), dim3(256), 0, s, workspace, C,
