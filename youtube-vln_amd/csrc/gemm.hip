@@ -416,7 +416,8 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         // 224x256: native instruction, K-contiguous A, launches of ONE round (measured: 4480x3072x768 189.7 -> 170.5 us; the 2400-tile LM decoder
         // gains nothing over 2160 tiles of 256x256 -- multi-round launches already overlap their tiles' fixed costs)
         const int64_t ntile = tile >= 5 ? cdiv(M, tile == 5 ? 224 : 160) * cdiv(N, 256) : 0;
-        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && ntile > 256))) continue;
+        // (M >= 4096: at 2304 rows -- cfg 2 with K = 1 -- the 160-row plans measured 2 % behind the 128x128 ones in the step, 308.7 -> 301.8 rows/s)
+        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && (ntile > 256 || M < 4096)))) continue;
         if (ta && tile == 3) continue;          // (256x128 was never measured with an M-contiguous A)
         // split-K: 128x128 always; 256x256 in the three-term form and -- round 2 -- for the native weight-gradient layout (ta):
         // 1024x1024x16128 323 -> 305 us, 2048x1024x16128 551 -> 505, 768x3072x4480 190 -> 178 (16 x 16, 32 x 8, 36 x 7 workgroups)
