@@ -1270,6 +1270,7 @@ using namespace ytvln;
 
 // ---- launches over one or two problems of equal (N, heads, d) ------------------------------------------------------------------
 static int launch_fwd(AttnLaunch& b, int np, hipStream_t s) {
+    if (np > 1 && b.p[1].Tk > b.p[0].Tk) std::swap(b.p[0], b.p[1]);          // forward workgroups walk key tiles: the long-key direction first (see launch_bwd)
     const AttnArgs& a0 = b.p[0];
     const int dp = dp_of(a0.d);
     bool drop = false;
@@ -1334,6 +1335,7 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
     // delta[n,h,q] = sum_c dctx.ctx is produced by the dQ kernel's prologue (it owns the query rows) and read by the dK/dV kernel that
     // follows it on the stream
     for (int i = 0; i < np; ++i) b.p[i].delta_out = const_cast<float*>(b.p[i].delta);
+    if (np > 1 && b.p[1].Tk > b.p[0].Tk) std::swap(b.p[0], b.p[1]);          // dQ workgroups walk key tiles: the long-key direction first
     {
         // one wave per workgroup and per SIMD (attn_bwd_dq_w1_body); option ATTN_W1 bit 1 clear: the two-wave form
         const bool w1 = (opt(OPT_ATTN_W1) & 2) && (a0.d == 128 || a0.d == 64) && maxTk <= 512;      // (unpadded heads, mask row in registers)
@@ -1349,6 +1351,11 @@ static int launch_bwd(AttnLaunch& b, int np, hipStream_t s) {
     // one wave per workgroup and per SIMD (attn_bwd_dkv_w1_body; option ATTN_W1 bit 2 clear: always the wave-pair form): unpadded fp32 heads, lse /
     // delta rows staged by one wave, and at least two rounds of the 1024 wave slots (a 1.3-round launch -- 3 key tiles x 448 heads -- pays for 2:
     // there the pair form, whose workgroups are half as long, loses less; option ATTN_W1_DKV_ANY = 1 takes the one-wave form regardless)
+    // Two directions in one launch: a dK/dV workgroup owns key tiles and walks the QUERY tiles, so the direction with the longer query sequence
+    // has the longer workgroups; those go first (the grid is handed out in order: long ones last would leave a tail of a few hundred long
+    // workgroups on a mostly idle chip -- 288-query x 80-key workgroups behind 80 x 288 ones: ~30 instead of ~24 tile times).  The forward / dQ
+    // launches walk KEY tiles; BertBiAttention already passes its long-key direction first.
+    if (np > 1 && b.p[1].Tq > b.p[0].Tq) std::swap(b.p[0], b.p[1]);
     const int64_t w1_waves = (cdiv(b.p[0].Tk, 32) + (np > 1 ? cdiv(b.p[1].Tk, 32) : 0)) * a0.heads * a0.N;
     const int64_t w1_slots = a0.d == 128 ? 1024 : 2048;          // (d = 64: 17 KB of LDS and < 256 registers per wave -> two per SIMD)
     const bool w1_fill = w1_waves * 100 >= cdiv(w1_waves, w1_slots) * w1_slots * 85;      // the last round at least ~85 % useful overall
