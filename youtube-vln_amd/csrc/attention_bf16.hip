@@ -586,6 +586,7 @@ static int bcheck(const char* who, const BAttnArgs& a) {
     } while (0)
 
 static int blaunch_fwd(BAttnLaunch& b, int np, hipStream_t s) {
+    if (np > 1 && b.p[1].Tk > b.p[0].Tk) std::swap(b.p[0], b.p[1]);          // long workgroups first (attention.hip launch_bwd): forward walks key tiles
     const BAttnArgs& a0 = b.p[0];
     bool drop = false;
     int maxTk = 0;
@@ -628,6 +629,7 @@ static int blaunch_bwd(BAttnLaunch& b, int np, hipStream_t s) {
         YT_REQUIRE(!drop || (b.p[i].keep && ((uintptr_t)b.p[i].keep & 127) == 0),
                    "attn_bwd_bf16: a launch with dropout needs the keep buffers its forward wrote in every problem");
     {
+        if (np > 1 && b.p[1].Tk > b.p[0].Tk) std::swap(b.p[0], b.p[1]);      // dQ walks key tiles: the long-key direction first
         b.gx0 = (int)cdiv(b.p[0].Tq, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tq, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
@@ -637,6 +639,7 @@ static int blaunch_bwd(BAttnLaunch& b, int np, hipStream_t s) {
         YT_BLAUNCH(battn_bwd_dq_kernel, lds);
     }
     {
+        if (np > 1 && b.p[1].Tq > b.p[0].Tq) std::swap(b.p[0], b.p[1]);      // dK/dV walks query tiles: the long-query direction first
         b.gx0 = (int)cdiv(b.p[0].Tk, 32);
         b.gx1 = np > 1 ? (int)cdiv(b.p[1].Tk, 32) : 1;
         b.nb0 = b.gx0 * a0.heads * a0.N;
