@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const LT* __restrict__ logi
     __shared__ float sh[8];
     const int row = blockIdx.x;
     const int64_t t = target[row];
+    if (t == ignore) {          // ~85 % of the masked-LM rows: their loss is 0 and ce_bwd_kernel never reads their log-sum-exp (block-uniform exit)
+        if (threadIdx.x == 0) { row_lse[row] = 0.f; row_loss[row] = 0.f; }
+        return;
+    }
     const LT* x = logits + (int64_t)row * ld;
     const float lse = block_lse(x, V, sh);
     if (threadIdx.x == 0) {
