@@ -991,6 +991,43 @@ def test_g16_cfg5_full_per_gpu_size_n224_forward(dev, lib, precision):
         close(total, g["loss/total"], LOSS_TOL, 0, "loss/total")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_g16b_cfg5_full_per_gpu_size_n224_backward(dev, lib, precision):
+    """BASELINE configs[4] at its OWN per-GPU size, BACKWARD (VERDICT r5 "missing" 6): 224 rows x 576 regions x 80 tokens on the FULL model,
+    one forward + backward of the four losses in ONE batch on the GPU against the reference's gradients (oracle/gen_golden_full.py g16b: the
+    real reference run in chunks of 4 items and re-assembled by linearity of the mean losses, checked against g16's forward losses).
+    fp32: every per-tensor gradient norm within 2e-4 relative, a 64-element strided slice of every gradient within 2e-4 of the tensor's
+    largest slice entry + 1e-7, the set of tensors without a gradient equal.  bf16-resident: norms within 5 % (10 % for the co-attention
+    query / key projections, see _bf16_check), never bit-equal to fp32."""
+    from ytvln import ops, synth
+    g = gold("g16b_cfg5_full_n224_grads.npz")
+    args = args_ns(**PRETRAIN)
+    model, W = build_lily(dev, FULL_CFG, args, seed=34)
+    batch = synth.to_torch(synth.make_batch(bs=32, K=7, T=80, frames=16, boxes=36, seed=44, ignore_rank_frac=0.0), dev)
+    if precision == "bf16":
+        _bf16_check(model, batch, args, g)
+        return
+    model.train()
+    outputs, total, per = losses_of(model, batch, args)
+    total.backward()
+    for k in ("vision", "language", "ranking", "traj"):
+        close(per[k], g["loss/" + k], LOSS_TOL, 0, "loss/" + k)
+    pd = dict(model.named_parameters())
+    assert {n for n, p in model.named_parameters() if p.grad is None} == set(g["unused"].tolist())
+    bad = []
+    for n, ref, sl in zip(g["grad_names"].tolist(), g["grad_norms"], g["grad_slices"]):
+        gr = pd[n].grad.detach().reshape(-1)
+        norm = float(gr.double().norm())
+        if abs(norm - float(ref)) > 2e-4 * float(ref) + 1e-6:
+            bad.append((n, "norm", norm, float(ref)))
+        st = max(1, gr.numel() // 64)
+        got = gr[::st][:64].float().cpu().numpy()
+        err = float(np.abs(got - sl[: got.size]).max())
+        if err > 2e-4 * float(np.abs(sl).max()) + 1e-7:
+            bad.append((n, "slice", err, float(np.abs(sl).max())))
+    assert not bad, bad[:10]
+
+
 def test_g11_cfg2_full_size_n56_gradients(dev, lib):
     """BASELINE configs[1] at the size bench.py runs: bs = 8 items x K = 7 = 56 rows, T = 80, R = 288, FULL model -- losses, logit slices
     and checksums, ALL per-tensor gradient norms and the post-AdamW parameter summaries against the reference (round 1 checked gradients

@@ -182,3 +182,15 @@ def test_g15_oracle_follows_the_reference_trajectory():
     assert runs.shape == (int(s["n_seeds"]), int(s["steps"]), 5) and np.isfinite(runs).all()
     assert np.allclose(runs.mean(0), s["mean"], atol=1e-5) and np.allclose(runs.std(0, ddof=1), s["std"], atol=1e-5)
     assert (s["std"][:, 0] > 0).all()          # dropout really was on: the seeds differ
+
+
+def test_g16b_gradient_fixture_is_the_backward_of_g16():
+    """The chunked reference backward at configs[4]'s own size (oracle/gen_golden_full.py g16b) re-assembles g16's forward losses, names
+    every parameter of the full model exactly once (gradient or `unused`), and its unused set is the reference's H3/H5 set of g10 / g11."""
+    f, b = gold("g16_cfg5_full_n224.npz"), gold("g16b_cfg5_full_n224_grads.npz")
+    for k in ("vision", "language", "ranking", "traj"):
+        assert abs(float(b["loss/" + k]) - float(f["loss/" + k])) <= 2e-5 * max(1.0, abs(float(f["loss/" + k])))
+    g10 = gold("g10_cfg5_long_n14.npz")
+    assert sorted(b["unused"].tolist()) == sorted(g10["unused"].tolist())
+    assert sorted(b["grad_names"].tolist()) == sorted(g10["grad_names"].tolist())
+    assert b["grad_slices"].shape == (len(b["grad_names"]), 64) and np.isfinite(b["grad_norms"]).all() and (b["grad_norms"] > 0).all()
