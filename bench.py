@@ -89,6 +89,14 @@ def parse():
     ap.add_argument("--host-probe", type=int, default=3, metavar="N",
                     help="N extra steps after the timed region (0: none), each enqueued into EMPTY queues (device synchronised first): wall and "
                          "CPU time of the enqueue alone = the host work of a step without back-pressure waits (tools/host8.py)")
+    ap.add_argument("--host-wait", choices=["blocking", "spin"], default="blocking",
+                    help="blocking (default): hipDeviceScheduleBlockingSync + the host paced two steps ahead of the device on blocking events "
+                         "(ytvln.misc.set_host_wait / StepPacer): a rank sleeps while its GPU works -- <= one core per rank; spin: the runtime's "
+                         "default (the host fills the stream's queue and spins for room: two cores per rank in round 5)")
+    ap.add_argument("--loop", choices=["graph", "reference"], default="graph",
+                    help="reference (not the headline): the body of the reference's train_epoch as it stands (utils/utils_init.py:199-268) on the "
+                         "drop-in modules -- eager launches, model.zero_grad(), every logged scalar read back with float() each step: what an "
+                         "import swap alone gives before the loop adopts train_step / hipGraph replay")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="(diagnostic, not a measurement configuration) run the N > 1 code path -- DataParallel wrapper, two-graph step, RCCL "
                          "all-reduce of the whole gradient arena through the C ABI communicator -- in a ONE-rank world on a single GPU")
@@ -209,6 +217,24 @@ class GemmTimer:
             s = shapes.setdefault((M, N, K, ta, tb), [0, 0.0, 0.0])
             s[0] += 1; s[1] += ms; s[2] += fl
         return tot_ms, tot_flop, len(self.records), shapes
+
+
+def thread_cpu_times() -> dict:
+    """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc/self/task): WHICH thread burns the host cores."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open(f"/proc/self/task/{tid}/stat").read()
+                name = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / tick)
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
 
 
 def effective_cores() -> int:
@@ -383,6 +409,14 @@ def main():
     dev_index = local_rank % ndev          # (ranks may share a device only in the gloo self-test below)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    from ytvln import misc as yt_misc
+    host_wait = a.host_wait
+    if a.host_wait == "blocking":
+        try:
+            yt_misc.set_host_wait(True, dev_index)
+        except RuntimeError as e:          # the flag is an optimisation of the HOST side; never a reason to lose the measurement
+            print(f"[bench] rank {rank}: blocking host wait unavailable ({e}); spinning", file=sys.stderr)
+            host_wait = "spin (blocking unavailable)"
     from ytvln import distributed as D
     collective = D.default_collective()
     dp_wrap = world > 1 or a.dp_selftest
@@ -469,8 +503,35 @@ def main():
         def step(i):
             return utils_init.train_step(runner, opt, sched, batch, args, i, all_options=True, loss_aware_heads=a.loss_aware_heads)
 
-    use_graph = a.graph in ("on", "auto") and not infer
-    execution = "eager launches"
+    if a.loop == "reference" and not infer:
+        from ytvln.utils_init import compute_metrics_independent, get_model_input
+
+        def step(i):      # noqa: F811 -- utils/utils_init.py:199-268 line by line (tensorboard / logger calls = the float() reads they imply)
+            outputs = runner(*get_model_input(batch))
+            loss = torch.tensor(0, device=dev).float()
+            rm = {"loss": {}, "accuracy": {}}
+            if args.masked_vision:
+                loss += compute_metrics_independent(batch, outputs, "vision", args, None, rm)
+            if args.masked_language:
+                loss += compute_metrics_independent(batch, outputs, "language", args, None, rm)
+            if args.ranking:
+                loss += compute_metrics_independent(batch, outputs, "ranking", args, None, rm)
+            if args.traj_judge:
+                loss += args.traj_loss_scale * compute_metrics_independent(batch, outputs, "traj", args, None, rm)
+            rm["loss/train"] = torch.tensor(0, device=dev).detach().float()
+            for item in rm["loss"].values():
+                rm["loss/train"] += item
+            loss.backward()
+            opt.step()
+            sched.step()
+            runner.zero_grad()
+            logged = [float(sched.get_last_lr()[0]), float(rm["loss/train"])] + [float(v) for v in rm["accuracy"].values()] + \
+                     [float(v) for v in rm["loss"].values()]          # writer.add_scalar(...) + logger.info(f"{...:.2f}") of the reference
+            return loss.detach(), logged
+
+    use_graph = a.graph in ("on", "auto") and not infer and a.loop == "graph"
+    execution = "eager launches" if a.loop == "graph" else \
+        "the reference's train_epoch body as it stands: eager launches, model.zero_grad(), logged scalars read back every step"
     eager_step = step
     if use_graph:
         # world == 1: hipGraph replay of the whole step (forward, losses, backward, fused AdamW); the host only uploads the
@@ -585,6 +646,8 @@ def main():
     power = PowerSampler(dev) if rank == 0 else None
     if power is not None:
         power.start()
+    pacer = yt_misc.StepPacer(2) if a.host_wait == "blocking" else None
+    threads0 = thread_cpu_times()
     t0 = time.perf_counter()
     c0 = time.thread_time()
     pc0 = time.process_time()
@@ -592,9 +655,13 @@ def main():
     for i in range(a.steps):
         e0 = time.perf_counter()
         loss, _ = step(a.warmup + i)
+        if pacer is not None:
+            pacer.tick()          # sleep (blocking event) until step i - 2 has finished: the queue never fills, nothing spins
         enq.append(time.perf_counter() - e0)
     host_enqueue = time.perf_counter() - t0          # wall time until the last step is enqueued: INCLUDES waiting for room in the stream's queue
     host_cpu = time.thread_time() - c0               # CPU time this thread spent enqueueing: what N ranks on one host really compete for
+    if pacer is not None:
+        pacer.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -602,6 +669,9 @@ def main():
     elapsed = time.perf_counter() - t0
     power_info = power.stop() if power is not None else None
     host_cpu_process = time.process_time() - pc0     # every thread of this rank until the steps have drained: + RCCL proxy / HIP runtime threads
+    threads1 = thread_cpu_times()
+    host_threads = sorted(((round(1000.0 * (threads1[t][1] - threads0.get(t, (threads1[t][0], 0.0))[1]) / a.steps, 2), threads1[t][0]) for t in threads1),
+                          reverse=True)[:4]          # the four busiest threads of this rank during the timed region: ms of CPU per step, name
     timer.on = ftimer.on = False
     elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)
     host_probe = None
@@ -730,6 +800,8 @@ def main():
         "host_cpu_process_ms_per_step": round(1000.0 * host_cpu_process / a.steps, 2),          # this rank, all threads (incl. RCCL proxy / runtime)
         "host_enqueue_ms_tail": {"p50": round(1000.0 * float(np.percentile(enq, 50)), 2), "max": round(1000.0 * max(enq), 2)},   # per step, this rank
         "host_cores_available": effective_cores(),
+        "host_wait": host_wait + (", host paced 2 steps ahead on blocking events" if pacer is not None else ""),
+        "host_busiest_threads_ms_per_step": [{"thread": n, "cpu_ms": v} for v, n in host_threads],
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
         "power": power_info,
     }
@@ -905,7 +977,9 @@ def main():
             # the loss-aware heads (LM / image logits only where the loss reads them: same losses and gradients).  NOT the headline.
             for tag, extra, note in (("h2d_overlap", ["--h2d", "overlap"], "batch re-uploaded from pinned host memory every step on a copy stream under the previous step"),
                                      ("h2d_compact", ["--h2d", "compact"], "compact batch (distinct frames once, un-masked tokens) uploaded every step, options expanded and masked on the device"),
-                                     ("loss_aware_heads", ["--loss-aware-heads"], "decoder / image-head logits only at the positions the losses read (identical losses and gradients)")):
+                                     ("loss_aware_heads", ["--loss-aware-heads"], "decoder / image-head logits only at the positions the losses read (identical losses and gradients)"),
+                                     ("reference_loop", ["--loop", "reference"], "the reference's train_epoch body as it stands on the drop-in modules (utils/utils_init.py:199-268): eager launches, "
+                                      "model.zero_grad(), every logged scalar read back each step -- what the import swap alone gives")):
                 try:
                     import subprocess
                     torch.cuda.empty_cache()

@@ -27,10 +27,18 @@
 extern "C" {
 #endif
 
-#define YTVLN_ABI_VERSION 1
+/* 2 (round 6): ytvln_attn_problem carries `keep` (added in round 5 without a bump: a version-1 binding paired with that library passed the
+ * check with a struct 8 bytes short), ytvln_attn_problem_size, ytvln_set_host_wait, ytvln_rccl_allreduce_slices (any dtype). */
+#define YTVLN_ABI_VERSION 2
 
 int ytvln_version(void);
 const char* ytvln_last_error(void);
+
+/* How the HOST waits for the device (hipSetDeviceFlags on `device`; one process per GPU as in utils/distributed.py:63-104, where N ranks share one
+ * host): blocking = 1 -> hipDeviceScheduleBlockingSync, a thread that waits in hipStreamSynchronize / hipDeviceSynchronize / hipEventSynchronize
+ * sleeps on an interrupt instead of spinning on a core; 0 -> the runtime's default (spin).  Host-side only; no kernel is affected.  Call it
+ * before the first stream / event of the process is created (ytvln.misc.set_host_wait does). */
+int ytvln_set_host_wait(int device, int blocking);
 
 /* Run-time options: the complete set of switches the library reads (kernel-form selection for tests and experiments; nothing a
  * production run has to touch).  An option starts from the environment variable YTVLN_<NAME> (read at first use) and can be set at any
@@ -261,6 +269,8 @@ typedef struct ytvln_attn_problem {
                         same problem; in a two-problem launch BOTH records need one as soon as either has p_drop > 0; ignored by the fp32 entry points (they
                         regenerate the hash) and by launches without dropout (may be NULL) */
 } ytvln_attn_problem;
+/* sizeof(ytvln_attn_problem) as the LIBRARY was built: a binding asserts it equals its own record size at load time */
+int64_t ytvln_attn_problem_size(void);
 int ytvln_attn_fwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
                         const int64_t* rng, void* stream);
 int ytvln_attn_bwd_pair(const ytvln_attn_problem* a, const ytvln_attn_problem* b, int N, int heads, int d, float scale,
@@ -348,6 +358,10 @@ int ytvln_rccl_allreduce(void* comm, void* buf, int64_t count, int dtype, int op
  * arena as ONE RCCL group: the buckets of an optimizer step without a host round trip between them. */
 int ytvln_rccl_allreduce_slices_f32(void* comm, float* base, const int64_t* offsets, const int64_t* counts, int nslices,
                                     void* stream);
+/* the same for an arena of any element type of the enum above (offsets / counts in ELEMENTS): the bf16 gradient exchange of the bf16-resident
+ * path (BASELINE configs[4]) moves half the bytes of the fp32 one over xGMI */
+int ytvln_rccl_allreduce_slices(void* comm, void* base, int dtype, const int64_t* offsets, const int64_t* counts, int nslices,
+                                void* stream);
 /* in-place byte broadcast from `root` (DDP's rank-0 weight broadcast at wrap time) */
 int ytvln_rccl_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
 int ytvln_rccl_async_error(void* comm);                /* 0 = healthy; negative + ytvln_last_error() otherwise                 */

@@ -36,7 +36,8 @@ def test_build_entry_point_compiles_and_loads():
     g.build()
     from ytvln import _lib
     lib = _lib.load()
-    assert lib.ytvln_version() == _lib.ABI_VERSION == 1
+    assert lib.ytvln_version() == _lib.ABI_VERSION == 2
+    assert lib.ytvln_attn_problem_size() == __import__("ctypes").sizeof(_lib.AttnProblem) == 192
     assert lib.ytvln_last_error() is not None
 
 
@@ -67,7 +68,13 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     with pytest.raises(RuntimeError, match="ytvln_ln_fwd_f32 failed"):
         _lib.call("ytvln_ln_fwd_f32", 16, None, 16, 16, 16, None, None, None, 4, 30, 1e-12, 0.0, 0.0, None, 0, None)   # H % 4 != 0
     assert lib.ytvln_gemm_workspace_elems(1024, 1024, 16128, 0) > 0
-    assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) == 2 * 256 * 256 * 256      # two banks of one partial tile per workgroup of a stream-K launch
+    assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) == 0      # no split, persistent kernel off (default): no scratch
+    prev = _lib.set_option("GEMM_SK", 1)
+    try:          # stream-K form on: two banks of one partial 256x256 tile per workgroup, one workgroup per CU (256 when no device is visible)
+        assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) % (2 * 256 * 256) == 0
+        assert lib.ytvln_gemm_workspace_elems(16128, 1024, 1024, 0) >= 2 * 8 * 256 * 256
+    finally:
+        _lib.set_option("GEMM_SK", prev)
     assert lib.ytvln_gemm_workspace_elems(100, 64, 64, 0) == 0
     assert lib.ytvln_ln_bwd_blocks(16128) == 768
 

@@ -389,9 +389,10 @@ static double plan_cost(int M, int N, int K, int tile, int sp, int epilogue = 0,
     const int kchunk = (int)cdiv(cdiv(K, sp), BK) * BK;
     const int splits = (int)cdiv(K, kchunk);
     const double blocks = (double)(cdiv(M, bm[tile]) * cdiv(N, bn[tile])) * splits;
-    const double waves = ceil(blocks / 256.0);
+    const double ncu = (double)sk_num_cus();          // 256 on MI355X (the plans pinned in tests/test_abi.py assume it)
+    const double waves = ceil(blocks / ncu);
     // the 4-wave tiles only reach their rate with 2-3 blocks co-resident on a CU (one block = one wave per SIMD)
-    const double need = tile == 1 ? 2.0 : tile == 2 ? 3.0 : 1.0, per_cu = std::max(1.0, blocks / 256.0);
+    const double need = tile == 1 ? 2.0 : tile == 2 ? 3.0 : 1.0, per_cu = std::max(1.0, blocks / ncu);
     const double occ = per_cu < need ? need / per_cu : 1.0;
     // fused activations read / write a second matrix in the epilogue: dearer for the 256-row tiles (64-128 KB per workgroup, no overlap)
     double tf = tfix[tile] + ((tile >= 3 && epilogue != YTVLN_EPI_NONE) ? 2.0 : 0.0);
@@ -417,7 +418,7 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         // gains nothing over 2160 tiles of 256x256 -- multi-round launches already overlap their tiles' fixed costs)
         const int64_t ntile = tile >= 5 ? cdiv(M, tile == 5 ? 224 : 160) * cdiv(N, 256) : 0;
         // (M >= 4096: at 2304 rows -- cfg 2 with K = 1 -- the 160-row plans measured 2 % behind the 128x128 ones in the step, 308.7 -> 301.8 rows/s)
-        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && (ntile > 256 || M < 4096)))) continue;
+        if (tile >= 5 && (x3 || ta || N < 256 || !opt(OPT_GEMM_T224) || (force_tile < 0 && (ntile > sk_num_cus() || M < 4096)))) continue;
         if (ta && tile == 3) continue;          // (256x128 was never measured with an M-contiguous A)
         // split-K: 128x128 always; 256x256 in the three-term form and -- round 2 -- for the native weight-gradient layout (ta):
         // 1024x1024x16128 323 -> 305 us, 2048x1024x16128 551 -> 505, 768x3072x4480 190 -> 178 (16 x 16, 32 x 8, 36 x 7 workgroups)
@@ -426,7 +427,7 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
             // (long contractions: not measured, left on the old plans; short ones lose: 4480x1024x768 x 3 splits of 256 measured 76 us against 72.5)
-            if (tile >= 5 && sp > 1 && force_tile < 0 && (ntile * sp > 256 || K > 4096 || K / sp < 512)) break;
+            if (tile >= 5 && sp > 1 && force_tile < 0 && (ntile * sp > sk_num_cus() || K > 4096 || K / sp < 512)) break;
             const double t = plan_cost(M, N, K, tile, sp, epilogue, x3, ta);
             // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
             if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp}; }
@@ -524,9 +525,10 @@ extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue)
                                 1);
     // (covers either A layout and the fp32x3 plans)
     int64_t need = splits > 1 ? (int64_t)splits * M * N + (int64_t)splits * ((M + 3) / 4 * 4) : 0;      // partial tiles + partial row sums of A
-    // the stream-K form of the persistent kernel (K-contiguous A): one partial tile per workgroup
-    // (sized for either tile and independent of the run-time options, so a caller may cache the figure)
-    if (M >= 256 && N >= 128) need = std::max<int64_t>(need, (int64_t)2 * sk_num_cus() * 256 * (N >= 256 ? 256 : 128));
+    // the stream-K form of the persistent kernel (K-contiguous A; opt-in GEMM_SK): one partial tile per workgroup, sized for either tile.
+    // Only while the option is on (134 MB per GEMM for a kernel that is off by default); a caller that caches the figure keys it
+    // by the option (ytvln.ops._gemm does).
+    if (opt(OPT_GEMM_SK) != 0 && M >= 256 && N >= 128) need = std::max<int64_t>(need, (int64_t)2 * sk_num_cus() * 256 * (N >= 256 ? 256 : 128));
     return need;
 }
 

@@ -48,6 +48,7 @@ struct BfArgs {
     int mnA, mnB;                // clamp extents of the operands in their M / N dimension (rounded up to 8 inside zero padding for k-major operands)
     int kvalidA, kvalidB;        // contraction indices below these are readable: K -- or, for a contraction-contiguous A with zero padding behind K, K rounded up to 8
     float* asum; float* asum_ws; // optional: asum[m] = sum_k A[k][m] of a k-major A
+    int stagger_ticks;           // > 0: every second octet of the launch's first round of workgroups starts this many 100 MHz ticks late (see the kernel)
 };
 
 constexpr int KT = 64;           // k-tile depth in bf16 elements
@@ -343,7 +344,10 @@ __device__ __forceinline__ BfCoord bf_decode(int bid, int tiles_m, int tiles_n, 
 }
 
 // ---- main kernel -----------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int WPS, typename CT>
+// FORM: where the LDS-DMA of the next operand tiles is issued.  0: inside the load phases (L01: B(kt+1), L23: A(kt+2)), as rounds 4-5 shipped it;
+// 1: A(kt+2) between the matrix instructions of M23; 2: also B(kt+1) between those of M01 -- the load phases then hold fragment reads only and
+// fit under the partner group's 16 matrix instructions (a DMA piece costs 60-185 cycles of issue in a phase that also carries 12 LDS reads).
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int WPS, typename CT, int FORM = 0>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g) {
     using TA = BfTile<BM, A_KC, NW>;
     using TB = BfTile<BN, B_KC, NW>;
@@ -367,6 +371,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + KT - 1) / KT;
     const int nfull = (kend - kbeg) / KT;                     // whole k-tiles: LDS-DMA; a last partial one goes through registers
+    if (g.stagger_ticks > 0 && blockIdx.x < 256u && ((blockIdx.x >> 3) & 1)) {
+        // De-synchronise the chip: with one workgroup per CU every CU of a many-round launch reaches its prologue (cold A panels from HBM) and
+        // its store burst at the same moment, round after round.  Half of the FIRST round starts half a tile late; later workgroups inherit the
+        // offset from the CU they replace, so one half's fixed costs run under the other half's main loop.
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)g.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+    }
 
     const bf16_t* pa[TA::NI];
     const bf16_t* pb[TB::NI];
@@ -452,6 +463,59 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
             for (int j = 0; j < TN; ++j) frb[u][j] = fb.get(Bs, j, half, s0 + u);
         }
     };
+    // the DMA pieces of one operand tile issued between the matrix instructions of a phase: piece i after matrix instruction 4 i + 1
+    auto matrix_phase_dma = [&](auto which, int kt_in, bool live) __attribute__((always_inline)) {
+        constexpr bool IS_A = decltype(which)::value;
+        constexpr int NIP = IS_A ? TA::NI : TB::NI;
+        constexpr int NMFMA = 2 * TM * TN;
+        char* S = nullptr;
+        if (live) {
+            if constexpr (IS_A) { S = ringA + slotA_in * SA; slotA_in = slotA_in + 1 == NSA ? 0 : slotA_in + 1; }
+            else { S = ringB + slotB_in * SB; slotB_in = slotB_in + 1 == NSB ? 0 : slotB_in + 1; }
+        }
+        const bool dma = live && kt_in < nfull;
+        if (live && !dma) {          // rare: the tile crosses K -- through registers, zero past the end
+            const int k0 = kbeg + kt_in * KT;
+#pragma unroll
+            for (int i = 0; i < NIP; ++i) {
+                if constexpr (IS_A) *reinterpret_cast<uint4*>(S + (wave * NIP + i) * 1024 + 16 * lane) = TA::tail(g.A, g.lda, g.mnA, m0, k0, wave * NIP + i, lane, g.kvalidA);
+                else *reinterpret_cast<uint4*>(S + (wave * NIP + i) * 1024 + 16 * lane) = TB::tail(g.B, g.ldb, g.mnB, n0, k0, wave * NIP + i, lane, g.kvalidB);
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);
+        static_for<NMFMA>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            constexpr int u = idx / (TM * TN), i = (idx / TN) % TM, j = idx % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[u][i], frb[u][j], acc[i][j], 0, 0, 0);
+            static_for<NIP>([&](auto pc) {          // piece pi behind matrix instruction floor(pi * NMFMA / NIP): evenly spread over the phase
+                constexpr int pi = decltype(pc)::value;
+                if constexpr ((pi * NMFMA) / NIP == idx) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma) {
+                        if constexpr (IS_A) { __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[pi], (lds_ptr_t)(S + (wave * NIP + pi) * 1024), 16, 0, 0); pa[pi] += sa; }
+                        else { __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[pi], (lds_ptr_t)(S + (wave * NIP + pi) * 1024), 16, 0, 0); pb[pi] += sb; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto asum_phase = [&]() __attribute__((always_inline)) {
+        if constexpr (!A_KC) {
+            if (do_asum) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t += (float)fra[u][i][e];
+                        asum[i] += t;
+                    }
+            }
+        }
+    };
     auto matrix_phase = [&]() __attribute__((always_inline)) {
         if constexpr (!A_KC) {
             if (do_asum) {          // wave-uniform: first tile column, first wave column (row sums of A: the bias gradient)
@@ -490,26 +554,42 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
         slotB_out = slotB_out + 1 == NSB ? 0 : slotB_out + 1;
         // ---- L01
         read_frags(As, Bs, 0);
-        if (kt + 1 < nk) issueB(kt + 1);
+        if constexpr (FORM < 2) { if (kt + 1 < nk) issueB(kt + 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- M01
-        matrix_phase();
+        if constexpr (FORM == 2) {
+            asum_phase();
+            matrix_phase_dma(std::false_type{}, kt + 1, kt + 1 < nk);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the K-tail form of the issue writes LDS through registers)
+        } else {
+            matrix_phase();
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- L23
         read_frags(As, Bs, 2);
-        if (kt + 2 < nk) {
-            issueA(kt + 2);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TA::NI) : "memory");
-        } else {
+        if constexpr (FORM == 0) {
+            if (kt + 2 < nk) {
+                issueA(kt + 2);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TA::NI) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+        } else {          // everything issued so far -- A(kt+1) in M23(kt-1), B(kt+1) in L01 / M01(kt) -- has landed before the barrier below
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- M23
-        matrix_phase();
+        if constexpr (FORM >= 1) {
+            asum_phase();
+            matrix_phase_dma(std::true_type{}, kt + 2, kt + 2 < nk);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            matrix_phase();
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     }
@@ -528,6 +608,41 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
         }
     }
     bf_epilogue<TM, TN, CT>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
+}
+
+// One launch function per (output type, main-loop FORM); forms 1 and 2 are instantiated in their own translation units (gemm_bf16_f1.hip,
+// gemm_bf16_f2.hip include this file with YT_BF16_FORM_TU), so the three sets of kernels build in parallel.
+template <typename CT, int FORM>
+void bf_launch_form(const BfArgs& g, int big, int transA, int transB, hipStream_t s) {
+    const dim3 grid((unsigned)(g.ntiles * g.splits)), blk(512);
+#define YT_BF(BMV, WPSV)                                                                                                                    \
+    do {                                                                                                                                    \
+        if (!transA && transB) hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, true, true, 8, WPSV, CT, FORM>), grid, blk, 0, s, g);          \
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, true, false, 8, WPSV, CT, FORM>), grid, blk, 0, s, g);   \
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, false, false, 8, WPSV, CT, FORM>), grid, blk, 0, s, g);   \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, false, true, 8, WPSV, CT, FORM>), grid, blk, 0, s, g);                           \
+    } while (0)
+    if (big) YT_BF(256, 2);
+    else YT_BF(128, 4);
+#undef YT_BF
+}
+
+#if defined(YT_BF16_FORM_TU)
+template void bf_launch_form<float, YT_BF16_FORM_TU>(const BfArgs&, int, int, int, hipStream_t);
+template void bf_launch_form<bf16_t, YT_BF16_FORM_TU>(const BfArgs&, int, int, int, hipStream_t);
+}  // namespace ytvln
+#else
+extern template void bf_launch_form<float, 1>(const BfArgs&, int, int, int, hipStream_t);
+extern template void bf_launch_form<bf16_t, 1>(const BfArgs&, int, int, int, hipStream_t);
+extern template void bf_launch_form<float, 2>(const BfArgs&, int, int, int, hipStream_t);
+extern template void bf_launch_form<bf16_t, 2>(const BfArgs&, int, int, int, hipStream_t);
+
+template <typename CT>
+static void bf_launch(const BfArgs& g, int big, int transA, int transB, hipStream_t s) {
+    const int form = opt(OPT_GEMM_BF16_FORM);
+    if (form == 2) bf_launch_form<CT, 2>(g, big, transA, transB, s);
+    else if (form == 1) bf_launch_form<CT, 1>(g, big, transA, transB, s);
+    else bf_launch_form<CT, 0>(g, big, transA, transB, s);
 }
 
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic; also finishes the per-split row sums of A
@@ -679,21 +794,6 @@ static BfPlan bf_plan(int M, int N, int K, int epilogue) {
     return p;
 }
 
-template <typename CT>
-static void bf_launch(const BfArgs& g, int big, int transA, int transB, hipStream_t s) {
-    const dim3 grid((unsigned)(g.ntiles * g.splits)), blk(512);
-#define YT_BF(BMV, WPSV)                                                                                                              \
-    do {                                                                                                                              \
-        if (!transA && transB) hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, true, true, 8, WPSV, CT>), grid, blk, 0, s, g);          \
-        else if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, true, false, 8, WPSV, CT>), grid, blk, 0, s, g);   \
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, false, false, 8, WPSV, CT>), grid, blk, 0, s, g);   \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<BMV, BMV, false, true, 8, WPSV, CT>), grid, blk, 0, s, g);                           \
-    } while (0)
-    if (big) YT_BF(256, 2);
-    else YT_BF(128, 4);
-#undef YT_BF
-}
-
 }  // namespace ytvln
 
 using namespace ytvln;
@@ -723,7 +823,7 @@ extern "C" int ytvln_gemm_bf16(const uint16_t* A, int64_t lda, int transA, const
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.epilogue = epilogue; g.beta = beta;
     g.splits = 1; g.kchunk = (int)cdiv(std::max(K, 1), KT) * KT; g.ws = nullptr; g.asum = nullptr; g.asum_ws = nullptr;
-    g.mnA = M; g.mnB = N; g.kvalidA = K; g.kvalidB = K;
+    g.mnA = M; g.mnB = N; g.kvalidA = K; g.kvalidB = K; g.stagger_ticks = 0;
     // Fast-path legality: 16-byte aligned operands whose rows start on 16-byte boundaries, and whole 16-byte granules:
     //   contraction-contiguous operand: K % 8 == 0 -- or, for A only, readable ZERO padding behind K up to lda (YTVLN_GEMM_A_ZERO_PADDED: the
     //     30522- and 1601-wide logit gradients as the A operand of the input-gradient GEMM);
@@ -764,6 +864,13 @@ extern "C" int ytvln_gemm_bf16(const uint16_t* A, int64_t lda, int transA, const
         if (asum_ok) g.asum = a_rowsum;
     }
     if (rowsum_done) *rowsum_done = g.asum != nullptr;
+    {   // GEMM_STAGGER = percent of one tile's main-loop time (1.6 us per k-tile on the 256x256 tile): launches of >= 3 rounds only
+        const int pct = opt(OPT_GEMM_STAGGER);
+        if (pct > 0 && plan.big && (int64_t)g.ntiles * g.splits >= 3 * 256) {
+            const int nk = (int)cdiv(std::min(K, g.kchunk), KT);
+            g.stagger_ticks = (int)(nk * 1.6 * pct);          // 100 ticks per us, pct / 100 of nk * 1.6 us
+        }
+    }
     if (c_dtype == YTVLN_DT_F32) bf_launch<float>(g, plan.big, transA, transB, s);
     else bf_launch<bf16_t>(g, plan.big, transA, transB, s);
     if (g.splits > 1) {
@@ -790,3 +897,4 @@ extern "C" int ytvln_cast_f32_bf16(const float* x, int64_t ldx, int64_t rows, in
     YT_LAUNCH_CHECK("cast_f32_bf16");
     return 0;
 }
+#endif  // YT_BF16_FORM_TU

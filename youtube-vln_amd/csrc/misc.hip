@@ -25,6 +25,7 @@ struct OptionEntry { const char* name; int dflt; };
 static const OptionEntry kOptions[OPT_COUNT] = {
     {"ATTN_W1", 7}, {"ATTN_W1_DKV_ANY", 0}, {"ATTN_DSPLIT", 1}, {"GEMM_TILE", -1}, {"GEMM_SPLITS", -1}, {"GEMM_SPLIT_MAP", 1}, {"GEMM_GENERIC", 0},
     {"GEMM_SW", 0}, {"GEMM_SK", 0}, {"GEMM_SK_TILE", -1}, {"GEMM_SK_GROUPS", 8}, {"GEMM_T224", 1},
+    {"GEMM_BF16_FORM", 0}, {"GEMM_STAGGER", 0},
 };
 static std::atomic<int> g_opt_value[OPT_COUNT];
 static std::atomic<int> g_opt_set[OPT_COUNT];          // 0: not read yet, 1: holds a value
@@ -68,4 +69,17 @@ extern "C" int ytvln_get_option(const char* name, int* value) {
 }
 
 extern "C" int ytvln_version(void) { return YTVLN_ABI_VERSION; }
+extern "C" int64_t ytvln_attn_problem_size(void) { return (int64_t)sizeof(ytvln_attn_problem); }
+
+extern "C" int ytvln_set_host_wait(int device, int blocking) {
+    using namespace ytvln;
+    YT_REQUIRE(device >= 0, "set_host_wait: bad device %d", device);
+    int prev = -1;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess) e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipSetDeviceFlags(blocking ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(-3, "set_host_wait: %s", hipGetErrorString(e)); }
+    return 0;
+}
 extern "C" const char* ytvln_last_error(void) { return ytvln::err_buf(); }

@@ -159,23 +159,30 @@ extern "C" int ytvln_rccl_allreduce(void* comm, void* buf, int64_t count, int dt
 }
 
 // Several contiguous slices of one buffer as ONE RCCL group (one launch train, no host round trip between the slices).
-extern "C" int ytvln_rccl_allreduce_slices_f32(void* comm, float* base, const int64_t* offsets, const int64_t* counts, int nslices,
-                                               void* stream) {
-    YT_REQUIRE(comm != nullptr && g_api.handle != nullptr, "ytvln_rccl_allreduce_slices_f32: no communicator");
-    YT_REQUIRE(nslices >= 0 && (nslices == 0 || (base && offsets && counts)), "ytvln_rccl_allreduce_slices_f32: bad arguments");
+extern "C" int ytvln_rccl_allreduce_slices(void* comm, void* base, int dtype, const int64_t* offsets, const int64_t* counts, int nslices,
+                                           void* stream) {
+    YT_REQUIRE(comm != nullptr && g_api.handle != nullptr, "ytvln_rccl_allreduce_slices: no communicator");
+    YT_REQUIRE(nslices >= 0 && (nslices == 0 || (base && offsets && counts)), "ytvln_rccl_allreduce_slices: bad arguments");
+    ncclDataType_t dt;
+    size_t esz;
+    YT_REQUIRE(to_nccl_type(dtype, &dt, &esz), "ytvln_rccl_allreduce_slices: unsupported dtype %d", dtype);
     if (nslices == 0) return 0;
     YT_NCCL(g_api.GroupStart(), "ncclGroupStart");
     ncclResult_t first = ncclSuccess;
     for (int i = 0; i < nslices; ++i) {
         if (counts[i] <= 0) continue;
-        ncclResult_t r = g_api.AllReduce(base + offsets[i], base + offsets[i], (size_t)counts[i], ncclFloat32, ncclSum, (ncclComm_t)comm,
-                                         as_stream(stream));
+        char* p = static_cast<char*>(base) + (size_t)offsets[i] * esz;
+        ncclResult_t r = g_api.AllReduce(p, p, (size_t)counts[i], dt, ncclSum, (ncclComm_t)comm, as_stream(stream));
         if (r != ncclSuccess && first == ncclSuccess) first = r;
     }
     ncclResult_t e = g_api.GroupEnd();
     if (first != ncclSuccess) return fail(-4, "ncclAllReduce (grouped): %s", g_api.GetErrorString(first));
     if (e != ncclSuccess) return fail(-4, "ncclGroupEnd: %s", g_api.GetErrorString(e));
     return 0;
+}
+extern "C" int ytvln_rccl_allreduce_slices_f32(void* comm, float* base, const int64_t* offsets, const int64_t* counts, int nslices,
+                                               void* stream) {
+    return ytvln_rccl_allreduce_slices(comm, base, YTVLN_DT_F32, offsets, counts, nslices, stream);
 }
 
 extern "C" int ytvln_rccl_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream) {

@@ -95,11 +95,14 @@ SIGNATURES = {
     "ytvln_rccl_init": [P, P, I64, I32, I32, I32],
     "ytvln_rccl_allreduce": [P, P, I64, I32, I32, P],
     "ytvln_rccl_allreduce_slices_f32": [P, P, P, P, I32, P],
+    "ytvln_rccl_allreduce_slices": [P, P, I32, P, P, I32, P],
+    "ytvln_set_host_wait": [I32, I32],
+    "ytvln_attn_problem_size": [],
     "ytvln_rccl_broadcast": [P, P, I64, I32, P],
     "ytvln_rccl_async_error": [P],
     "ytvln_rccl_destroy": [P],
 }
-RESTYPES = {"ytvln_gemm_workspace_elems": I64, "ytvln_attn_keep_bytes": I64, "ytvln_gemm_sk_ctl_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
+RESTYPES = {"ytvln_attn_problem_size": I64, "ytvln_gemm_workspace_elems": I64, "ytvln_attn_keep_bytes": I64, "ytvln_gemm_sk_ctl_elems": I64, "ytvln_gemm_bf16_workspace_elems": I64, "ytvln_rccl_library_path": C.c_char_p, "ytvln_option_name": C.c_char_p}
 DT_F32, DT_F64, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3, 4
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128
@@ -107,7 +110,7 @@ RCCL_UNIQUE_ID_BYTES = 128
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
 GEMM_A_ZERO_PADDED = 1
 GEMM_SPLIT_BF16X3 = 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -138,6 +141,8 @@ def load():
         fn.restype = RESTYPES.get(name, I32)
     if lib.ytvln_version() != ABI_VERSION:
         raise YtvlnLibraryError(f"ABI mismatch: library {lib.ytvln_version()} != binding {ABI_VERSION}")
+    if lib.ytvln_attn_problem_size() != C.sizeof(AttnProblem):          # a record the library would read past
+        raise YtvlnLibraryError(f"ytvln_attn_problem: library {lib.ytvln_attn_problem_size()} bytes != binding {C.sizeof(AttnProblem)}")
     _lib = lib
     _FN.update({name: getattr(lib, name) for name in SIGNATURES})
     return lib
@@ -169,9 +174,23 @@ def options() -> dict:
     return out
 
 
+_OPTION_CACHE = {}
+
+
+def option(name: str) -> int:
+    """Current value of one run-time option (cached on the Python side; `set_option` is the only writer after the first read)."""
+    v = _OPTION_CACHE.get(name)
+    if v is None:
+        c = C.c_int(0)
+        call("ytvln_get_option", name.encode(), C.byref(c))
+        v = _OPTION_CACHE[name] = c.value
+    return v
+
+
 def set_option(name: str, value: int) -> int:
     """Set a run-time option (kernel-form selection for tests / experiments); returns the previous value."""
     prev = C.c_int(0)
     call("ytvln_get_option", name.encode(), C.byref(prev))
     call("ytvln_set_option", name.encode(), int(value))
+    _OPTION_CACHE.pop(name[6:] if name.startswith("YTVLN_") else name, None)
     return prev.value

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 
 def set_seed(args) -> None:
@@ -29,3 +29,37 @@ def set_seed(args) -> None:
 def is_default_gpu(args) -> bool:
     """utils/misc.py:46-50, as written there: true without data parallelism, and on every rank but 0 with it."""
     return getattr(args, "local_rank", -1) == -1 or dist.get_rank() != 0
+
+
+def set_host_wait(blocking: bool = True, device=None) -> None:
+    """How this process waits for its GPU.  One process per GPU (utils/distributed.py:63-104) means N ranks share one host's cores: with the
+    runtime's default a rank that has filled its stream's queue, or sits in `torch.cuda.synchronize()`, SPINS on a core (measured round 5:
+    221 ms of process CPU per 110 ms step = two cores per rank).  `blocking=True` = hipDeviceScheduleBlockingSync through the C ABI
+    (`ytvln_set_host_wait`): waiting threads sleep on an interrupt.  Host-side only; call it after `torch.cuda.set_device(...)` and before
+    the training loop.  Pair it with `StepPacer` so that the enqueueing thread waits on a blocking EVENT instead of a full queue."""
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device("cuda", device).index if not isinstance(device, int) else device
+    _lib.call("ytvln_set_host_wait", int(device), 1 if blocking else 0)
+
+
+class StepPacer:
+    """Keeps the host at most `depth` steps ahead of the device and makes it SLEEP while it waits: after step i has been enqueued the host
+    blocks (hipEventBlockingSync) on the end of step i - depth.  The queue is never full, so no thread spins for queue room, and the device
+    never runs dry (a step is ~100 ms of GPU work; enqueueing one takes ~1-5 ms).  `tick()` after every enqueued step, `drain()` at the end."""
+
+    def __init__(self, depth: int = 2):
+        import collections
+        self.depth = max(1, int(depth))
+        self._events = collections.deque()
+
+    def tick(self, stream=None) -> None:
+        ev = torch.cuda.Event(blocking=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        self._events.append(ev)
+        while len(self._events) > self.depth:
+            self._events.popleft().synchronize()
+
+    def drain(self) -> None:
+        while self._events:
+            self._events.popleft().synchronize()

@@ -333,14 +333,15 @@ def _gemm(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias=None, aux=None, 
     """fp32 operands (native fp32 matrix instruction, or the three-bf16-term form under "fp32x3").  `rowsum` = an [M] tensor that should
     receive sum_k op(A)[m, k] (the bias gradient riding on a weight-gradient GEMM, ytvln_gemm_f32_rowsum); returns True when the launch
     produced it, False when the caller has to run `colsum` itself."""
-    key = (M, N, K, epi)
+    sk = _lib.option("GEMM_SK") != 0          # the persistent kernel (opt-in): its partial-tile scratch and control block exist only then
+    key = (M, N, K, epi, sk)
     need = _WS_CACHE.get(key)
     if need is None:
         need = _WS_CACHE[key] = int(_lib.load().ytvln_gemm_workspace_elems(M, N, K, epi))
     ws = torch.empty(need, dtype=torch.float32, device=C.device) if need else None      # split-K / stream-K scratch (caching allocator)
     if _MATMUL_PRECISION == "fp32x3":
         flags = int(flags) | GEMM_SPLIT_BF16X3
-    ctl = _sk_ctl(C.device)
+    ctl = _sk_ctl(C.device) if sk else None
     if rowsum is not None:
         done = ctypes.c_int(0)
         call("ytvln_gemm_f32_sk", _ptr(A), lda, int(transA), _ptr(B), ldb, int(transB), _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux,
@@ -364,10 +365,16 @@ def _sk_ctl(device):
         if torch.cuda.is_current_stream_capturing():
             return None
         n = int(_lib.load().ytvln_gemm_sk_ctl_elems())
-        pair = _SK_CTL[device] = (torch.zeros(n, dtype=torch.int32, device=device), torch.zeros(n, dtype=torch.int32, device=device))
+        # (block of the main role, block of the side role, the stream that owns the main role = the one the first launch was enqueued on)
+        pair = _SK_CTL[device] = (torch.zeros(n, dtype=torch.int32, device=device), torch.zeros(n, dtype=torch.int32, device=device), _stream())
         torch.cuda.synchronize(device)
     side = TwoStream._side.get(device)
-    return pair[1] if (side is not None and _stream() == side.cuda_stream) else pair[0]
+    cur = _stream()
+    if side is not None and cur == side.cuda_stream:
+        return pair[1]
+    # any other stream than the two roles (a user stream, a communication stream, a second graph): two launches sharing one block could run at
+    # the same time -- those take the launch-per-tile kernel
+    return pair[0] if cur == pair[2] else None
 
 
 def colsum(x: Tensor, M: int, N: int, ld: int, out: Optional[Tensor] = None) -> Tensor:

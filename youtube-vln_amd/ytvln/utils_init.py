@@ -236,10 +236,13 @@ def train_epoch(epoch, model, optimizer, scheduler, data_loader, writer, default
     device = next(model.parameters()).device
     model.train()
     model.zero_grad()
+    from .misc import StepPacer
+    pacer = StepPacer(2)          # the host sleeps on a blocking event two steps back instead of spinning for queue room (one core per rank)
     for step, batch in enumerate(data_loader):
         all_options = bool(batch[13].all()) if not batch[13].is_cuda else None      # decided on the host, no GPU sync
         batch = tuple(t.to(device, non_blocking=True) if hasattr(t, "to") else t for t in batch)
         loss, reduced_metrics = train_step(model, optimizer, scheduler, batch, args, step, logger, all_options)
+        pacer.tick()
         if default_gpu and writer is not None:
             global_step = step + epoch * len(data_loader)
             if "head_row_overflow" in reduced_metrics and float(reduced_metrics["head_row_overflow"]) > 0:
