@@ -93,6 +93,12 @@ def parse():
                     help="blocking (default): hipDeviceScheduleBlockingSync + the host paced two steps ahead of the device on blocking events "
                          "(ytvln.misc.set_host_wait / StepPacer): a rank sleeps while its GPU works -- <= one core per rank; spin: the runtime's "
                          "default (the host fills the stream's queue and spins for room: two cores per rank in round 5)")
+    ap.add_argument("--pace", default="event:2", metavar="MODE:DEPTH",
+                    help="host pacing under --host-wait blocking (ytvln.misc.StepPacer): MODE event (blocking hipEventSynchronize) or poll (query + sleep "
+                         "1 ms), DEPTH = steps the host may run ahead of the device")
+    ap.add_argument("--graphs", type=int, default=1, choices=[1, 2],
+                    help="1 GPU: number of instantiated copies of the captured step replayed in turn (2: a replay never has to wait for the previous "
+                         "launch of the SAME executable graph to finish)")
     ap.add_argument("--loop", choices=["graph", "reference"], default="graph",
                     help="reference (not the headline): the body of the reference's train_epoch as it stands (utils/utils_init.py:199-268) on the "
                          "drop-in modules -- eager launches, model.zero_grad(), every logged scalar read back with float() each step: what an "
@@ -545,14 +551,18 @@ def main():
                 eager_step(i)
             torch.cuda.synchronize()
             if not dp_wrap:
-                graph = torch.cuda.CUDAGraph()
-                static = {}
-                with torch.cuda.graph(graph):
-                    static["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
-                                                                 loss_aware_heads=a.loss_aware_heads)
-                torch.cuda.synchronize()
+                graphs = []
+                for _ in range(a.graphs):
+                    graph = torch.cuda.CUDAGraph()
+                    static = {}
+                    with torch.cuda.graph(graph):
+                        static["loss"], _ = utils_init.train_step(runner, opt, None, batch, args, 0, all_options=True,
+                                                                     loss_aware_heads=a.loss_aware_heads)
+                    torch.cuda.synchronize()
+                    graphs.append((graph, static))
 
                 def graph_step(i):
+                    graph, static = graphs[i % len(graphs)]
                     opt.prepare_replay()
                     graph.replay()
                     sched.step()
@@ -646,7 +656,9 @@ def main():
     power = PowerSampler(dev) if rank == 0 else None
     if power is not None:
         power.start()
-    pacer = yt_misc.StepPacer(2) if a.host_wait == "blocking" else None
+    pace_mode, pace_depth = a.pace.split(":")
+    pacer = yt_misc.StepPacer(int(pace_depth), pace_mode) if a.host_wait == "blocking" else None
+    t_step = t_tick = 0.0
     threads0 = thread_cpu_times()
     t0 = time.perf_counter()
     c0 = time.thread_time()
@@ -654,9 +666,13 @@ def main():
     enq = []
     for i in range(a.steps):
         e0 = time.perf_counter()
+        c_0 = time.thread_time()
         loss, _ = step(a.warmup + i)
+        c_1 = time.thread_time()
         if pacer is not None:
-            pacer.tick()          # sleep (blocking event) until step i - 2 has finished: the queue never fills, nothing spins
+            pacer.tick()          # sleep until step i - depth has finished: the queue never fills, nothing spins
+        t_step += c_1 - c_0
+        t_tick += time.thread_time() - c_1
         enq.append(time.perf_counter() - e0)
     host_enqueue = time.perf_counter() - t0          # wall time until the last step is enqueued: INCLUDES waiting for room in the stream's queue
     host_cpu = time.thread_time() - c0               # CPU time this thread spent enqueueing: what N ranks on one host really compete for
@@ -800,7 +816,8 @@ def main():
         "host_cpu_process_ms_per_step": round(1000.0 * host_cpu_process / a.steps, 2),          # this rank, all threads (incl. RCCL proxy / runtime)
         "host_enqueue_ms_tail": {"p50": round(1000.0 * float(np.percentile(enq, 50)), 2), "max": round(1000.0 * max(enq), 2)},   # per step, this rank
         "host_cores_available": effective_cores(),
-        "host_wait": host_wait + (", host paced 2 steps ahead on blocking events" if pacer is not None else ""),
+        "host_wait": host_wait + (f", host paced {a.pace} (StepPacer mode:depth)" if pacer is not None else ""),
+        "host_thread_cpu_ms_per_step": {"in_step_call": round(1000.0 * t_step / a.steps, 2), "in_pacer": round(1000.0 * t_tick / a.steps, 2)},
         "host_busiest_threads_ms_per_step": [{"thread": n, "cpu_ms": v} for v, n in host_threads],
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
         "power": power_info,

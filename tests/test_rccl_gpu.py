@@ -70,7 +70,7 @@ def _plain_run(dev, steps=3, precision="fp32", wide=False):
 def _plain_run_body(dev, steps, U, get_optimization, wide):
     model, args = _build(dev, wide)
     args.learning_rate = 1e-3
-    opt, sched, _, _ = get_optimization(args, model, 10, None)
+    opt, sched, _, _ = get_optimization(args, model, 10 if steps <= 3 else steps + 5, None)
     batch = _batch(dev)
     for step in range(steps):
         U.train_step(model, opt, sched, batch, args, step, all_options=True)
@@ -92,6 +92,10 @@ def _worker(case, port, q):
         from ytvln import ops
         ops.set_matmul_precision(precision or "fp32")
         collective, mode = case.split(":")
+        nreplay = 2
+        if "#" in mode:                           # "phased#50": that many replays (soak of the phased exchange: comm stream, per-group AdamW)
+            mode, _, nr = mode.partition("#")
+            nreplay = int(nr)
         metrics = mode.endswith("+metrics")       # the reference's default: local_rank != -1 and --skip_all_reduce off -> logged metrics are all-reduced
         mode = mode.replace("+metrics", "")
         if mode == "phased3":           # explicit cut list: a text-only cut below the co-attention layer, the layer itself, an image-only cut above
@@ -108,7 +112,7 @@ def _worker(case, port, q):
         info = {}
         if dp.comm is not None:
             info["library"] = dp.comm.library
-        opt, sched, _, _ = get_optimization(args, model, 10, None)
+        opt, sched, _, _ = get_optimization(args, model, 10 if nreplay <= 2 else nreplay + 6, None)     # (the schedule of _plain_run_body)
         dp.attach(opt)
         batch = _batch(dev)
         if mode == "eager":
@@ -128,9 +132,16 @@ def _worker(case, port, q):
                 info["groups"] = [sum(hi - lo for lo, hi in g) for g in gs._group_slices]
                 info["arena"] = int(opt.flat_grad().numel())
                 info["params"] = sum(p.numel() for p in model.parameters() if p.grad is not None or True)
-            for step in range(2):
+            mem = []
+            for step in range(nreplay):
                 loss = gs.step(sched)
+                if step in (4, nreplay - 1):
+                    torch.cuda.synchronize()
+                    mem.append((torch.cuda.memory_allocated(), torch.cuda.memory_reserved()))
             assert torch.isfinite(loss).item()
+            if nreplay > 5:
+                assert mem[0] == mem[-1], f"device memory moved during the replays: {mem}"          # constant footprint over the soak
+                info["mem"] = mem
             if mode == "phased":        # the cut points are gone once the phases are recorded: an eager step sees the uncut graph
                 assert all(not m.cut_after for m in model.modules() if hasattr(m, "cut_after"))
         torch.cuda.synchronize()
@@ -152,7 +163,7 @@ def _worker(case, port, q):
         raise e
 
 
-@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "rccl:phased", "rccl:phased3", "torch:eager", "torch:split",
+@pytest.mark.parametrize("case", ["rccl:eager", "rccl:split", "rccl:single", "rccl:phased", "rccl:phased3", "rccl:phased#50", "rccl:phased3#50", "torch:eager", "torch:split",
                                   "rccl:eager+metrics", "rccl:split+metrics", "rccl:phased+metrics", "rccl:eager@bf16", "rccl:phased@bf16"])
 def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     ctx = mp.get_context("spawn")
@@ -164,7 +175,9 @@ def test_one_rank_rccl_world_equals_plain_run(dev, lib, case):
     assert status == "ok", got
     assert p.exitcode == 0
     case, _, precision = case.partition("@")
-    ref = _plain_run(dev, precision=precision or "fp32")
+    nreplay = int(case.partition("#")[2] or 2)
+    case = case.partition("#")[0]
+    ref = _plain_run(dev, steps=1 + nreplay, precision=precision or "fp32")
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())     # identity exchange, grad_scale 1: bit-identical
     if precision:
         assert not np.array_equal(ref, _plain_run(dev, wide=True)), "the bf16-resident run must differ from the fp32 one"

@@ -343,6 +343,9 @@ __device__ __forceinline__ BfCoord bf_decode(int bid, int tiles_m, int tiles_n, 
     return c;
 }
 
+#if defined(YT_BF16_SHARED_ONLY)
+}  // namespace ytvln
+#else
 // ---- main kernel -----------------------------------------------------------------------------------------------------------------------
 // FORM: where the LDS-DMA of the next operand tiles is issued.  0: inside the load phases (L01: B(kt+1), L23: A(kt+2)), as rounds 4-5 shipped it;
 // 1: A(kt+2) between the matrix instructions of M23; 2: also B(kt+1) between those of M01 -- the load phases then hold fragment reads only and
@@ -636,11 +639,16 @@ extern template void bf_launch_form<float, 1>(const BfArgs&, int, int, int, hipS
 extern template void bf_launch_form<bf16_t, 1>(const BfArgs&, int, int, int, hipStream_t);
 extern template void bf_launch_form<float, 2>(const BfArgs&, int, int, int, hipStream_t);
 extern template void bf_launch_form<bf16_t, 2>(const BfArgs&, int, int, int, hipStream_t);
+// 32-deep k-tiles in five-slot rings, three tiles in flight (gemm_bf16_h.hip)
+template <typename CT> void bf_launch_h(const BfArgs& g, int big, int transA, int transB, hipStream_t s);
+extern template void bf_launch_h<float>(const BfArgs&, int, int, int, hipStream_t);
+extern template void bf_launch_h<bf16_t>(const BfArgs&, int, int, int, hipStream_t);
 
 template <typename CT>
 static void bf_launch(const BfArgs& g, int big, int transA, int transB, hipStream_t s) {
     const int form = opt(OPT_GEMM_BF16_FORM);
-    if (form == 2) bf_launch_form<CT, 2>(g, big, transA, transB, s);
+    if (form == 3) bf_launch_h<CT>(g, big, transA, transB, s);
+    else if (form == 2) bf_launch_form<CT, 2>(g, big, transA, transB, s);
     else if (form == 1) bf_launch_form<CT, 1>(g, big, transA, transB, s);
     else bf_launch_form<CT, 0>(g, big, transA, transB, s);
 }
@@ -898,3 +906,4 @@ extern "C" int ytvln_cast_f32_bf16(const float* x, int64_t ldx, int64_t rows, in
     return 0;
 }
 #endif  // YT_BF16_FORM_TU
+#endif  // YT_BF16_SHARED_ONLY

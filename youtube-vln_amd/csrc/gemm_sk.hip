@@ -49,12 +49,13 @@ __device__ __forceinline__ void store16_sc1(uint32_t voff, f32x4 v, const void* 
     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");      // (s_nop 4: see epi_store)
 }
 
-__device__ __forceinline__ void load16(f32x4& d, uint32_t voff, const void* sbase) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait16(f32x4 (&b)[4]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+// four 16-byte loads (scalar bases + one per-lane offset) AND their wait in ONE statement: the destination registers are defined for the
+// compiler only once the data has landed, whatever the register allocator does around the statement (the 128x128 form of this
+// kernel has a scratch segment)
+__device__ __forceinline__ void load16x4(f32x4 (&b)[4], uint32_t voff, const void* s0, const void* s1, const void* s2, const void* s3) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %6\n\tglobal_load_dwordx4 %2, %4, %7\n\t"
+                 "global_load_dwordx4 %3, %4, %8\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(s3) : "memory");
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, bool SK, int WPS = 2>
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_sk_kernel(const GemmArgs g,
             stamp();                              // main loop of the piece done
             const TileCoord tc = tile_coord(tb + c_tile, g.tiles_m, g.tiles_n);
             if (!SK || (c_k0 == 0 && c_k == nk)) {
-                gemm_epilogue<TM, TN>(g, acc, tc.m * BM + wm0, tc.n * BN + wn0, l31, half, 0);
+                gemm_epilogue<TM, TN, BM != 128>(g, acc, tc.m * BM + wm0, tc.n * BN + wn0, l31, half, 0);
             } else if constexpr (SK) {
                 // ---- a piece of a shared tile: dump the accumulators in fragment order (write-through: visible on every XCD once acknowledged) ------
                 // Both the producers (k0 > 0) and the head (k0 == 0) do this: the head then rebuilds the tile from memory, 32x32 sub-tile by
@@ -253,9 +254,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_sk_kernel(const GemmArgs g,
                         f32x16 sum[1][1];
                         {
                             f32x4 buf[4];         // (a thread reads back exactly the 16-byte pieces it wrote itself)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) load16(buf[q], voff, base + (size_t)(sk.G + r) * (SLOT * 4) + (size_t)(gi * 4 + q) * (NW * 64 * 16));
-                            wait16<0>(buf);
+                            {
+                                const char* const b0 = base + (size_t)(sk.G + r) * (SLOT * 4) + (size_t)(gi * 4) * (NW * 64 * 16);
+                                load16x4(buf, voff, b0, b0 + (size_t)(NW * 64 * 16), b0 + (size_t)2 * (NW * 64 * 16), b0 + (size_t)3 * (NW * 64 * 16));
+                            }
                             typedef float f32x8 __attribute__((ext_vector_type(8)));
                             const f32x8 lo = __builtin_shufflevector(buf[0], buf[1], 0, 1, 2, 3, 4, 5, 6, 7);
                             const f32x8 hi = __builtin_shufflevector(buf[2], buf[3], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -264,15 +266,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_sk_kernel(const GemmArgs g,
 #pragma unroll 1
                         for (int j = r + 1; j < jend; ++j) {
                             f32x4 buf[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) load16(buf[q], voff, base + (size_t)j * (SLOT * 4) + (size_t)(gi * 4 + q) * (NW * 64 * 16));
-                            wait16<0>(buf);
+                            {
+                                const char* const b0 = base + (size_t)j * (SLOT * 4) + (size_t)(gi * 4) * (NW * 64 * 16);
+                                load16x4(buf, voff, b0, b0 + (size_t)(NW * 64 * 16), b0 + (size_t)2 * (NW * 64 * 16), b0 + (size_t)3 * (NW * 64 * 16));
+                            }
                             typedef float f32x8 __attribute__((ext_vector_type(8)));
                             const f32x8 lo = __builtin_shufflevector(buf[0], buf[1], 0, 1, 2, 3, 4, 5, 6, 7);
                             const f32x8 hi = __builtin_shufflevector(buf[2], buf[3], 0, 1, 2, 3, 4, 5, 6, 7);
                             sum[0][0] += __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                         }
-                        gemm_epilogue<1, 1>(g, sum, tc.m * BM + wm0 + 32 * (gi / TN), tc.n * BN + wn0 + 32 * (gi % TN), l31, half, 0);
+                        gemm_epilogue<1, 1, BM != 128>(g, sum, tc.m * BM + wm0 + 32 * (gi / TN), tc.n * BN + wn0 + 32 * (gi % TN), l31, half, 0);
                     }
                     if (tid == 0)
                         for (int j = r + 1; j < jend; ++j)

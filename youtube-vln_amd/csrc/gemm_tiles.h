@@ -257,7 +257,10 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& g, f32x16 (&ac
     });
 }
 
-template <int TM, int TN>
+// HAND = false: interior tiles that READ a matrix (beta, x GELU', x ReLU') take epilogue_body's compiler-counted loads instead of the
+// hand-counted ones of epilogue_interior.  For kernels that are allowed a scratch segment (_build.py SCRATCH_OK): a register the allocator
+// spills or copies between a hand-issued load and its hand-counted wait is read before the data lands.
+template <int TM, int TN, bool HAND = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int half, int split) {
     const bool interior = row0 + 32 * TM <= g.M && col0 + 32 * TN <= g.N;
     if (g.splits > 1) {      // raw partial sums; bias / beta are applied by splitk_reduce_kernel in a fixed order
@@ -298,7 +301,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
     }
 #define YT_EPI(E)                                                                        \
     case E:                                                                              \
-        if (interior) { if (g.beta != 0.f) epilogue_interior<TM, TN, E, true>(g, acc, row0, col0, l31, half); else epilogue_interior<TM, TN, E, false>(g, acc, row0, col0, l31, half); } \
+        if (interior) {                                                                  \
+            constexpr bool READS = E == YTVLN_EPI_MUL_DGELU || E == YTVLN_EPI_MUL_DRELU;  \
+            if (!HAND && (READS || g.beta != 0.f)) epilogue_body<TM, TN, E, true>(g, acc, row0, col0, l31, half); \
+            else if (g.beta != 0.f) epilogue_interior<TM, TN, E, true>(g, acc, row0, col0, l31, half); else epilogue_interior<TM, TN, E, false>(g, acc, row0, col0, l31, half); } \
         else epilogue_body<TM, TN, E, false>(g, acc, row0, col0, l31, half);             \
         break;
     switch (g.epilogue) {
@@ -307,7 +313,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
         YT_EPI(YTVLN_EPI_MUL_DGELU)
         YT_EPI(YTVLN_EPI_MUL_DRELU)
         default:
-            if (interior) { if (g.beta != 0.f) epilogue_interior<TM, TN, YTVLN_EPI_NONE, true>(g, acc, row0, col0, l31, half); else epilogue_interior<TM, TN, YTVLN_EPI_NONE, false>(g, acc, row0, col0, l31, half); }
+            if (interior) {
+                if (!HAND && g.beta != 0.f) epilogue_body<TM, TN, YTVLN_EPI_NONE, true>(g, acc, row0, col0, l31, half);
+                else if (g.beta != 0.f) epilogue_interior<TM, TN, YTVLN_EPI_NONE, true>(g, acc, row0, col0, l31, half); else epilogue_interior<TM, TN, YTVLN_EPI_NONE, false>(g, acc, row0, col0, l31, half); }
             else epilogue_body<TM, TN, YTVLN_EPI_NONE, false>(g, acc, row0, col0, l31, half);
             break;
     }

@@ -49,6 +49,49 @@ def _headers_mtime() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
+# Kernels whose epilogues issue loads from hand-written asm and wait for them with a hand-counted s_waitcnt (gemm_tiles.h epilogue_interior,
+# gemm_bf16.hip bf_epilogue_interior): the destination registers are only safe while the register allocator neither spills nor reloads anything
+# between the load and the wait.  A kernel without a scratch segment cannot do either, so the build REFUSES one that has scratch.
+AUDITED_KERNELS = ("gemm_dma_kernel", "gemm_bf16_kernel", "gemm_bf16_h_kernel", "gemm_sw_kernel", "gemm_sk_kernel")
+
+
+# ... except where the kernel was written for it: the 128x128 form of the persistent kernel (opt-in GEMM_SK, 2-4 spilled registers at its 128-register
+# budget) takes the compiler-counted epilogue loads (gemm_epilogue<..., HAND = false>) and issues its partial-tile loads together with their wait
+SCRATCH_OK = ("gemm_sk_kernelILi128ELi128E",)
+
+
+def parse_resource_usage(stderr: str) -> dict:
+    """{mangled kernel name: {"vgprs", "agprs", "sgprs", "scratch", "vgpr_spill", "sgpr_spill", "lds", "occupancy"}} from the remarks of
+    -Rpass-analysis=kernel-resource-usage."""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch", "VGPRs Spill": "vgpr_spill",
+            "SGPRs Spill": "sgpr_spill", "LDS Size [bytes/block]": "lds", "Occupancy [waves/SIMD]": "occupancy"}
+    for line in stderr.splitlines():
+        m = re.search(r"remark: .*Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][^:]*): (\d+) \[-Rpass", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def audit_gemm_kernels(src: str, obj: str, stderr: str) -> None:
+    import json
+    usage = parse_resource_usage(stderr)
+    with open(obj[:-2] + ".usage.json", "w") as f:
+        json.dump(usage, f, indent=0, sort_keys=True)
+    bad = {k: v for k, v in usage.items() if any(a in k for a in AUDITED_KERNELS) and not any(a in k for a in SCRATCH_OK)
+           and (v.get("scratch", 0) or v.get("vgpr_spill", 0))}
+    if bad:
+        raise RuntimeError(f"{os.path.basename(src)}: kernels with hand-counted epilogue loads must not use scratch (a spill between such a load "
+                           f"and its wait reads the register before the data lands): {bad}")
+    if not any(any(a in k for a in AUDITED_KERNELS) for k in usage):
+        raise RuntimeError(f"{os.path.basename(src)}: no kernel-resource-usage remarks parsed (compiler output format changed?)")
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -61,10 +104,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        audited = os.path.basename(src).startswith("gemm")
+        cmd = [hipcc, *FLAGS, *(["-Rpass-analysis=kernel-resource-usage"] if audited else []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        if audited:
+            audit_gemm_kernels(src, obj, r.stderr)
         return src
 
     if jobs:

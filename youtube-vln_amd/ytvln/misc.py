@@ -44,22 +44,34 @@ def set_host_wait(blocking: bool = True, device=None) -> None:
 
 
 class StepPacer:
-    """Keeps the host at most `depth` steps ahead of the device and makes it SLEEP while it waits: after step i has been enqueued the host
-    blocks (hipEventBlockingSync) on the end of step i - depth.  The queue is never full, so no thread spins for queue room, and the device
-    never runs dry (a step is ~100 ms of GPU work; enqueueing one takes ~1-5 ms).  `tick()` after every enqueued step, `drain()` at the end."""
+    """Keeps the host at most `depth` steps ahead of the device and lets it SLEEP while it waits: after step i has been enqueued the host waits
+    for the end of step i - depth.  mode "event": hipEventSynchronize on a blocking event (sleeps on an interrupt under
+    `set_host_wait(True)`); mode "poll": `event.query()` every `poll_ms` with `time.sleep` in between (never spins, whatever the runtime's wait
+    policy; costs up to poll_ms of latency, which `depth` >= 1 hides).  `tick()` after every enqueued step, `drain()` at the end."""
 
-    def __init__(self, depth: int = 2):
+    def __init__(self, depth: int = 2, mode: str = "event", poll_ms: float = 1.0):
         import collections
-        self.depth = max(1, int(depth))
+        if mode not in ("event", "poll"):
+            raise ValueError(mode)
+        self.depth = max(0, int(depth))
+        self.mode, self.poll_s = mode, poll_ms * 1e-3
         self._events = collections.deque()
+
+    def _wait(self, ev) -> None:
+        if self.mode == "event":
+            ev.synchronize()
+            return
+        import time
+        while not ev.query():
+            time.sleep(self.poll_s)
 
     def tick(self, stream=None) -> None:
         ev = torch.cuda.Event(blocking=True)
         ev.record(stream if stream is not None else torch.cuda.current_stream())
         self._events.append(ev)
         while len(self._events) > self.depth:
-            self._events.popleft().synchronize()
+            self._wait(self._events.popleft())
 
     def drain(self) -> None:
         while self._events:
-            self._events.popleft().synchronize()
+            self._wait(self._events.popleft())
