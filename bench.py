@@ -118,6 +118,9 @@ def make_args(flags):
     return types.SimpleNamespace(**a)
 
 
+import threading
+
+
 class PowerSampler:
     """Package power and shader clock of the device this rank computes on, read from the hwmon node under its PCI address
     (/sys/bus/pci/devices/<bdf>/hwmon/*: power1_input in microwatts, freq1_input in Hz, power1_cap) at 20 Hz by a host thread while the timed
@@ -136,6 +139,7 @@ class PowerSampler:
         except Exception:
             self.hw = None
         self.p, self.f, self.on = [], [], False
+        self.tid, self.cpu_s = None, 0.0
         self._thread = threading.Thread(target=self._run, daemon=True) if self.hw else None
 
     def _read(self, name):
@@ -146,6 +150,21 @@ class PowerSampler:
             return None
 
     def _run(self):
+        # (a hwmon read of the SMU busy-waits in the driver for tens of ms: this thread shows up as a core's worth of CPU in the process totals.  It is
+        #  the MEASUREMENT's thread, not the path's -- named, and its CPU time is reported separately and excluded from host_cpu_process_ms_per_step)
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(15, b"bench-power", 0, 0, 0)
+            self.tid = threading.get_native_id()
+        except Exception:
+            pass
+        c0 = time.thread_time()
+        try:
+            self._loop()
+        finally:
+            self.cpu_s = time.thread_time() - c0
+
+    def _loop(self):
         while self.on:
             p, f = self._read("power1_input"), self._read("freq1_input")
             if p is not None:
@@ -685,6 +704,8 @@ def main():
     elapsed = time.perf_counter() - t0
     power_info = power.stop() if power is not None else None
     host_cpu_process = time.process_time() - pc0     # every thread of this rank until the steps have drained: + RCCL proxy / HIP runtime threads
+    sampler_cpu = power.cpu_s if power is not None else 0.0
+    host_cpu_process = max(0.0, host_cpu_process - sampler_cpu)          # minus the bench's own power-sampling thread (see PowerSampler._run)
     threads1 = thread_cpu_times()
     host_threads = sorted(((round(1000.0 * (threads1[t][1] - threads0.get(t, (threads1[t][0], 0.0))[1]) / a.steps, 2), threads1[t][0]) for t in threads1),
                           reverse=True)[:4]          # the four busiest threads of this rank during the timed region: ms of CPU per step, name
@@ -819,6 +840,7 @@ def main():
         "host_wait": host_wait + (f", host paced {a.pace} (StepPacer mode:depth)" if pacer is not None else ""),
         "host_thread_cpu_ms_per_step": {"in_step_call": round(1000.0 * t_step / a.steps, 2), "in_pacer": round(1000.0 * t_tick / a.steps, 2)},
         "host_busiest_threads_ms_per_step": [{"thread": n, "cpu_ms": v} for v, n in host_threads],
+        "bench_power_sampler_cpu_ms_per_step": round(1000.0 * sampler_cpu / a.steps, 2),          # excluded from host_cpu_process_ms_per_step
         "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
         "power": power_info,
     }

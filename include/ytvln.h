@@ -156,6 +156,11 @@ int64_t ytvln_gemm_bf16_workspace_elems(int M, int N, int K, int epilogue);
 int ytvln_gemm_bf16(const uint16_t* A, int64_t lda, int transA, const uint16_t* B, int64_t ldb, int transB, void* C, int64_t ldc,
                     int c_dtype, const float* bias, uint16_t* aux, int64_t ldaux, int M, int N, int K, int epilogue, float beta,
                     float* workspace, int64_t workspace_elems, int flags, float* a_rowsum, int* rowsum_done, void* stream);
+/* Diagnostics: when `buffer` (128 uint32, device) is non-NULL, bf16-output forward-layout launches on the 256x256 tile run an instrumented build of
+ * the kernel in which waves 0 and 4 of workgroup `block` record s_memtime (shader cycles, low 32 bits) for k-tiles 8..15 at the eight phase
+ * boundaries of each k-tile selected by `mask` (bit 2i: own work of phase i done, bit 2i+1: the barrier behind it released; phases L01 M01
+ * L23 M23): buffer[64 * group + 8 * (kt - 8) + point].  NULL switches it off (default).  tools/gemm_bf16_probe.py prints the timeline. */
+int ytvln_gemm_bf16_probe(uint32_t* buffer, int block, int mask);
 /* out[r][c] = bf16(x[r][c]), round to nearest even: network inputs that arrive as fp32 (the 2048-d region features, once per step) and
  * parameters that are not inside the optimizer's arenas yet (the steps before the first optimizer step). */
 int ytvln_cast_f32_bf16(const float* x, int64_t ldx, int64_t rows, int cols, uint16_t* out, int64_t ldo, void* stream);

@@ -128,6 +128,9 @@ __device__ __forceinline__ Split3 split3(const float4 u, const float4 v) {
     return s;
 }
 
+#ifndef YT_GEMM_DMA_SPREAD
+#define YT_GEMM_DMA_SPREAD 1
+#endif
 template <int BM, int BN, bool A_KC, bool B_KC, int NW, int KB, int NS, int WPS, bool X3 = false, int WN = 2>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g) {
     using TA = DmaTile<BM, A_KC, NW, KB>;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
     int st_in = 0;      // ring slot the next issue() fills
-    auto issue = [&](int kt) {
+    auto issue = [&](int kt, bool advance = true) {
         float* As = smem + st_in * STAGE;
         float* Bs = As + SA;
         st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
@@ -187,18 +190,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
 #pragma unroll
         for (int i = 0; i < TA::NI; ++i) {
             if (TA::own(wave, i)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[i], (lds_ptr_t)(As + (wave * TA::NI + i) * 256), 16, 0, 0);
-            pa[i] += sa;
+            pa[i] += advance ? sa : 0;
         }
 #pragma unroll
         for (int i = 0; i < TB::NI; ++i) {
             if (TB::own(wave, i)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[i], (lds_ptr_t)(Bs + (wave * TB::NI + i) * 256), 16, 0, 0);
-            pb[i] += sb;
+            pb[i] += advance ? sb : 0;
         }
     };
 
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) issue(t);
+        if (t < nk) issue(t, !YT_GEMM_DMA_SPREAD || X3 || t + 1 < nk);          // (SPREAD re-requests the last tile: the pointers never leave the matrix)
     int st_out = 0;     // ring slot the MFMAs read
     for (int kt = 0; kt < nk; ++kt) {
         // my pieces of tile kt have landed (NS-2 younger tiles may stay in flight); after the barrier everybody's have, and
@@ -206,7 +209,40 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         if (NS > 2 && nk - kt - 1 >= NS - 2) wait_vmcnt<(NS - 2) * NPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+#if YT_GEMM_DMA_SPREAD
+        // SPREAD: the next tile's LDS-DMA pieces are not issued here in one burst -- both waves of every SIMD did that at the same moment, behind
+        // the barrier, with the matrix pipe idle (8 pieces x 2 waves x 30-60 cycles of issue: the ~1500 cycles a k-tile measured over its 16384
+        // of matrix time) -- but one at a time between the matrix instructions of the first k-groups (native path below; X3 keeps the burst).
+        const bool inc = kt + NS - 1 < nk;
+        float* const As_in = smem + st_in * STAGE;
+        float* const Bs_in = As_in + SA;
+        if (X3) { if (inc) issue(kt + NS - 1); }
+        else if (inc) {
+            st_in = (st_in + 1 == NS) ? 0 : st_in + 1;
+            if (tail_here && kbeg + (kt + NS) * KB > g.K) {
+#pragma unroll
+                for (int i = 0; i < TA::NI; ++i) pa[i] = TA::src(g.A, g.lda, g.mnA, m0, kbeg + (kt + NS - 1) * KB, wave, lane, i, g.K - 1);
+#pragma unroll
+                for (int i = 0; i < TB::NI; ++i) pb[i] = TB::src(g.B, g.ldb, g.mnB, n0, kbeg + (kt + NS - 1) * KB, wave, lane, i, g.K - 1);
+            }
+        }
+        // piece p of the incoming tile (A pieces first); past the last tile the same request with a zero pointer step (a slot nobody reads any more):
+        // no branch inside the matrix stream
+        const int64_t sa_in = kt + NS < nk ? sa : 0, sb_in = kt + NS < nk ? sb : 0;          // (no step past the last tile: the re-request stays inside the matrix)
+        auto issue_piece = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int pidx = decltype(pc)::value;
+            if constexpr (pidx < TA::NI) {
+                if (TA::own(wave, pidx)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pa[pidx], (lds_ptr_t)(As_in + (wave * TA::NI + pidx) * 256), 16, 0, 0);
+                pa[pidx] += sa_in;
+            } else if constexpr (pidx < NPT) {
+                constexpr int q = pidx - TA::NI;
+                if (TB::own(wave, q)) __builtin_amdgcn_global_load_lds((gbl_ptr_t)pb[q], (lds_ptr_t)(Bs_in + (wave * TB::NI + q) * 256), 16, 0, 0);
+                pb[q] += sb_in;
+            }
+        };
+#else
         if (kt + NS - 1 < nk) issue(kt + NS - 1);
+#endif
         const float* As = smem + st_out * STAGE;
         const float* Bs = As + SA;
         st_out = (st_out + 1 == NS) ? 0 : st_out + 1;
@@ -266,6 +302,33 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = TB::frag(Bs, wn0, j, l31, half, sg);
+#if YT_GEMM_DMA_SPREAD
+            // pieces [sg * PPG, (sg + 1) * PPG) of the incoming tile, spread over the first half of the k-groups: one behind each accumulator's four
+            // matrix instructions (256 cycles of the pipe per accumulator against 30-60 of issue), order pinned
+            constexpr int NGH = NG >= 2 ? NG / 2 : 1, PPG = (NPT + NGH - 1) / NGH;
+            static_for<TM * TN>([&](auto ijc) {
+                constexpr int ij = decltype(ijc)::value, i = ij / TN, j = ij % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                if constexpr (ij < PPG) {
+                    if (sg < NGH) {          // (sg is a constant after unrolling)
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for<NGH>([&](auto gc) {
+                            constexpr int gsel = decltype(gc)::value;
+                            if (sg == gsel) {          // a wave with fewer accumulators than pieces per group issues several behind one accumulator
+                                static_for<(PPG + TM * TN - 1) / (TM * TN)>([&](auto rc) {
+                                    constexpr int off = ij + decltype(rc)::value * TM * TN;
+                                    if constexpr (off < PPG) issue_piece(std::integral_constant<int, gsel * PPG + off>{});
+                                });
+                            }
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            });
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -275,6 +338,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
+#endif
         }
         }
     }
@@ -291,6 +355,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             }
         }
     }
+#if YT_GEMM_DMA_SPREAD
+    if (!X3) wait_vmcnt<0>();          // the trailing (repeated) requests have landed before this workgroup's LDS is handed on
+#endif
     gemm_epilogue<TM, TN>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
 }
 

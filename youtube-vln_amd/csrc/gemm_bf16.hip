@@ -49,6 +49,7 @@ struct BfArgs {
     int kvalidA, kvalidB;        // contraction indices below these are readable: K -- or, for a contraction-contiguous A with zero padding behind K, K rounded up to 8
     float* asum; float* asum_ws; // optional: asum[m] = sum_k A[k][m] of a k-major A
     int stagger_ticks;           // > 0: every second octet of the launch's first round of workgroups starts this many 100 MHz ticks late (see the kernel)
+    uint32_t* probe; int probe_block, probe_mask;      // diagnostics (ytvln_gemm_bf16_probe): phase time stamps of waves 0 and 4 of this workgroup
 };
 
 constexpr int KT = 64;           // k-tile depth in bf16 elements
@@ -350,7 +351,7 @@ __device__ __forceinline__ BfCoord bf_decode(int bid, int tiles_m, int tiles_n, 
 // FORM: where the LDS-DMA of the next operand tiles is issued.  0: inside the load phases (L01: B(kt+1), L23: A(kt+2)), as rounds 4-5 shipped it;
 // 1: A(kt+2) between the matrix instructions of M23; 2: also B(kt+1) between those of M01 -- the load phases then hold fragment reads only and
 // fit under the partner group's 16 matrix instructions (a DMA piece costs 60-185 cycles of issue in a phase that also carries 12 LDS reads).
-template <int BM, int BN, bool A_KC, bool B_KC, int NW, int WPS, typename CT, int FORM = 0>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW, int WPS, typename CT, int FORM = 0, bool PROBE = false>
 __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g) {
     using TA = BfTile<BM, A_KC, NW>;
     using TB = BfTile<BN, B_KC, NW>;
@@ -456,6 +457,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
     //   * every wave waits for its own pieces of tile kt+1 in L23(kt); group 0 first reads that tile two barriers later, group 1 three.
     //   vector memory retires in order and B(kt+1) is issued before A(kt+2): "at most NI_A outstanding" = tile kt+1 complete, A(kt+2) in flight.
     const int grp = wave >> 2;                                   // waves 0-3 / 4-7 (wave-uniform SGPR)
+    // PROBE: waves 0 and 4 of workgroup probe_block stamp s_memtime (shader cycles, low 32 bits) at the start and end of each phase's own
+    // work for k-tiles 8..15 -- 8 stamps per k-tile into the 64 lanes of one register, written out at the end: [own work ends | barrier released]
+    uint32_t ts = 0;
+    const bool probing = PROBE && g.probe != nullptr && (int)blockIdx.x == g.probe_block && (wave & 3) == 0;
+    auto stamp = [&](int kt, int p) __attribute__((always_inline)) {
+        if constexpr (PROBE) {
+            if (probing && kt >= 8 && kt < 16 && ((g.probe_mask >> p) & 1)) {
+                const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime();
+                ts = lane == (kt - 8) * 8 + p ? now : ts;
+            }
+        }
+    };
     bf16x8 fra[2][TM], frb[2][TN];
     auto read_frags = [&](const char* __restrict__ As, const char* __restrict__ Bs, int s0) __attribute__((always_inline)) {
 #pragma unroll
@@ -560,7 +573,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
         if constexpr (FORM < 2) { if (kt + 1 < nk) issueB(kt + 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        stamp(kt, 0);
         __builtin_amdgcn_s_barrier();
+        stamp(kt, 1);
         // ---- M01
         if constexpr (FORM == 2) {
             asum_phase();
@@ -570,7 +585,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
             matrix_phase();
         }
         __builtin_amdgcn_sched_barrier(0);
+        stamp(kt, 2);
         __builtin_amdgcn_s_barrier();
+        stamp(kt, 3);
         // ---- L23
         read_frags(As, Bs, 2);
         if constexpr (FORM == 0) {
@@ -584,7 +601,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+        stamp(kt, 4);
         __builtin_amdgcn_s_barrier();
+        stamp(kt, 5);
         // ---- M23
         if constexpr (FORM >= 1) {
             asum_phase();
@@ -594,7 +613,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
             matrix_phase();
         }
         __builtin_amdgcn_sched_barrier(0);
+        stamp(kt, 6);
         __builtin_amdgcn_s_barrier();
+        stamp(kt, 7);
+    }
+    if constexpr (PROBE) {
+        if (probing) g.probe[grp * 64 + lane] = ts;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();                  // (every wave executes the same number of barriers)
     if constexpr (!A_KC) {
@@ -643,10 +667,26 @@ extern template void bf_launch_form<bf16_t, 2>(const BfArgs&, int, int, int, hip
 template <typename CT> void bf_launch_h(const BfArgs& g, int big, int transA, int transB, hipStream_t s);
 extern template void bf_launch_h<float>(const BfArgs&, int, int, int, hipStream_t);
 extern template void bf_launch_h<bf16_t>(const BfArgs&, int, int, int, hipStream_t);
+// four waves of 128x128, one per SIMD (gemm_bf16_w4.hip): 256x256 tiles only
+bool bf_launch_w4(const BfArgs& g, int transA, int transB, hipStream_t s);          // false: no instantiation for this layout
+
+static uint32_t* g_bf_probe = nullptr;
+static int g_bf_probe_block = 0, g_bf_probe_mask = 0xff;
 
 template <typename CT>
-static void bf_launch(const BfArgs& g, int big, int transA, int transB, hipStream_t s) {
+static void bf_launch(const BfArgs& g0, int big, int transA, int transB, hipStream_t s) {
+    BfArgs g = g0;
+    g.probe = nullptr; g.probe_block = 0; g.probe_mask = 0;
     const int form = opt(OPT_GEMM_BF16_FORM);
+    if (form == 44) { g.probe = g_bf_probe; g.probe_block = g_bf_probe_block; g.probe_mask = g_bf_probe_mask; }
+    if constexpr (std::is_same<CT, bf16_t>::value) {
+        if (g_bf_probe && big && !transA && transB && form == 0) {          // diagnostics: the forward layout of the 256x256 tile with phase stamps
+            g.probe = g_bf_probe; g.probe_block = g_bf_probe_block; g.probe_mask = g_bf_probe_mask;
+            hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, true, true, 8, 2, bf16_t, 0, true>), dim3((unsigned)(g.ntiles * g.splits)), dim3(512), 0, s, g);
+            return;
+        }
+    }
+    if ((form == 4 || (form >= 41 && form <= 44)) && big && std::is_same<CT, bf16_t>::value && bf_launch_w4(g, transA, transB, s)) return;
     if (form == 3) bf_launch_h<CT>(g, big, transA, transB, s);
     else if (form == 2) bf_launch_form<CT, 2>(g, big, transA, transB, s);
     else if (form == 1) bf_launch_form<CT, 1>(g, big, transA, transB, s);
@@ -805,6 +845,11 @@ static BfPlan bf_plan(int M, int N, int K, int epilogue) {
 }  // namespace ytvln
 
 using namespace ytvln;
+
+extern "C" int ytvln_gemm_bf16_probe(uint32_t* buffer, int block, int mask) {
+    g_bf_probe = buffer; g_bf_probe_block = block; g_bf_probe_mask = mask;
+    return 0;
+}
 
 extern "C" int64_t ytvln_gemm_bf16_workspace_elems(int M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -52,7 +52,7 @@ def _headers_mtime() -> float:
 # Kernels whose epilogues issue loads from hand-written asm and wait for them with a hand-counted s_waitcnt (gemm_tiles.h epilogue_interior,
 # gemm_bf16.hip bf_epilogue_interior): the destination registers are only safe while the register allocator neither spills nor reloads anything
 # between the load and the wait.  A kernel without a scratch segment cannot do either, so the build REFUSES one that has scratch.
-AUDITED_KERNELS = ("gemm_dma_kernel", "gemm_bf16_kernel", "gemm_bf16_h_kernel", "gemm_sw_kernel", "gemm_sk_kernel")
+AUDITED_KERNELS = ("gemm_dma_kernel", "gemm_bf16_kernel", "gemm_bf16_h_kernel", "gemm_bf16_w4_kernel", "gemm_sw_kernel", "gemm_sk_kernel")
 
 
 # ... except where the kernel was written for it: the 128x128 form of the persistent kernel (opt-in GEMM_SK, 2-4 spilled registers at its 128-register

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ytvln_gemm_f32_sk": [P, I64, I32, P, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P, I64, I32, P, P, P, P],
     "ytvln_gemm_sk_plan": [I32, I32, I32, I32, I32, P, P, P, P, P],
     "ytvln_gemm_probe": [P],
+    "ytvln_gemm_bf16_probe": [P, I32, I32],
     "ytvln_colsum_f32": [P, I64, I32, I32, P, I64, I32, P],
     "ytvln_colsum_by_index_f32": [P, I64, P, I64, P, I32, I32, I32, P, I32, P],
     "ytvln_scatter_add_rows_f32": [P, I64, P, I32, I32, P, I64, P],
