@@ -244,6 +244,18 @@ class GemmTimer:
         return tot_ms, tot_flop, len(self.records), shapes
 
 
+_THREAD_BIRTH = {}
+
+
+def mark_threads(stage: str) -> None:
+    """Remember during which stage of the run each thread of this process first existed (diagnostic for host_busiest_threads_ms_per_step)."""
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            _THREAD_BIRTH.setdefault(int(tid), stage)
+    except OSError:
+        pass
+
+
 def thread_cpu_times() -> dict:
     """{tid: (name, user + system CPU seconds)} of every thread of this process (/proc/self/task): WHICH thread burns the host cores."""
     out = {}
@@ -432,8 +444,11 @@ def main():
     torch.set_num_threads(max(1, effective_cores() // max(1, world)))
     ndev = torch.cuda.device_count()
     dev_index = local_rank % ndev          # (ranks may share a device only in the gloo self-test below)
+    mark_threads("interpreter start-up (python, torch import)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    torch.zeros(1, device=dev)
+    mark_threads("HIP runtime initialisation (first device allocation)")
     from ytvln import misc as yt_misc
     host_wait = a.host_wait
     if a.host_wait == "blocking":
@@ -510,6 +525,7 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
+    mark_threads("model / optimizer construction")
     timer = GemmTimer()
     ftimer = FamilyTimer()
     if not a.no_kernel_timing:
@@ -613,9 +629,11 @@ def main():
             use_graph = False
             step = eager_step
 
+    mark_threads("eager steps + graph capture")
     for i in range(a.warmup):
         loss, _ = step(i)
     torch.cuda.synchronize()
+    mark_threads("warm-up steps (graph replays)")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -707,7 +725,9 @@ def main():
     sampler_cpu = power.cpu_s if power is not None else 0.0
     host_cpu_process = max(0.0, host_cpu_process - sampler_cpu)          # minus the bench's own power-sampling thread (see PowerSampler._run)
     threads1 = thread_cpu_times()
-    host_threads = sorted(((round(1000.0 * (threads1[t][1] - threads0.get(t, (threads1[t][0], 0.0))[1]) / a.steps, 2), threads1[t][0]) for t in threads1),
+    mark_threads("timed steps")
+    host_threads = sorted(((round(1000.0 * (threads1[t][1] - threads0.get(t, (threads1[t][0], 0.0))[1]) / a.steps, 2),
+                            threads1[t][0] + (" [main]" if t == os.getpid() else "") + " <" + _THREAD_BIRTH.get(t, "?") + ">") for t in threads1),
                           reverse=True)[:4]          # the four busiest threads of this rank during the timed region: ms of CPU per step, name
     timer.on = ftimer.on = False
     elapsed = control_reduce(elapsed, dist.ReduceOp.MAX)

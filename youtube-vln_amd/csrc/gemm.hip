@@ -128,6 +128,20 @@ __device__ __forceinline__ Split3 split3(const float4 u, const float4 v) {
     return s;
 }
 
+#ifndef YT_GEMM_PROBE
+#define YT_GEMM_PROBE 0
+#endif
+#if YT_GEMM_PROBE
+// measurement build (tools/gemm_f32_probe.py, -DYT_GEMM_PROBE=1): waves 0 and 4 of workgroup 3 of EVERY launch stamp s_memtime per k-tile at
+// [top | barrier released | k-group 0 issued | 1 | 2 | 3] for k-tiles 4..13 into this buffer (64 words per wave)
+__device__ uint32_t g_f32_probe[128];
+#endif
+#ifndef YT_GEMM_PRIO
+#define YT_GEMM_PRIO 1          // 1 (shipped): the younger half of the workgroup (waves NW/2..) at s_setprio 1 for the whole loop -- the probe shows the older wave of
+                                // every SIMD winning the matrix pipe, finishing its k-tile ~4500 cycles early and parking at the barrier while its partner runs
+                                // alone; priority for the younger half measured +0.5 % on the GEMM family (profiles/round6_gemm_prio_ab.log); 2 (priority
+                                // alternating per k-group) measured -2.5 %; 0 = none
+#endif
 #ifndef YT_GEMM_DMA_SPREAD
 #define YT_GEMM_DMA_SPREAD 1
 #endif
@@ -203,12 +217,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) issue(t, !YT_GEMM_DMA_SPREAD || X3 || t + 1 < nk);          // (SPREAD re-requests the last tile: the pointers never leave the matrix)
     int st_out = 0;     // ring slot the MFMAs read
+#if YT_GEMM_PROBE
+    uint32_t ts = 0;
+    const bool probing = blockIdx.x == 3 && (wave & 3) == 0 && !X3;
+#define YT_STAMP(P) do { if (probing && kt >= 4 && kt < 14) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); ts = lane == (kt - 4) * 6 + (P) ? now_ : ts; } } while (0)
+#else
+#define YT_STAMP(P) do { } while (0)
+#endif
+#if YT_GEMM_PRIO == 1
+    if (!X3 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        YT_STAMP(0);
         // my pieces of tile kt have landed (NS-2 younger tiles may stay in flight); after the barrier everybody's have, and
         // everybody is done reading the slot tile kt+NS-1 is about to overwrite (it held tile kt-1)
         if (NS > 2 && nk - kt - 1 >= NS - 2) wait_vmcnt<(NS - 2) * NPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        YT_STAMP(1);
 #if YT_GEMM_DMA_SPREAD
         // SPREAD: the next tile's LDS-DMA pieces are not issued here in one burst -- both waves of every SIMD did that at the same moment, behind
         // the barrier, with the matrix pipe idle (8 pieces x 2 waves x 30-60 cycles of issue: the ~1500 cycles a k-tile measured over its 16384
@@ -291,6 +317,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
         } else {
 #pragma unroll
         for (int sg = 0; sg < NG; ++sg) {
+#if YT_GEMM_PRIO == 2
+            if (((sg & 1) != 0) == (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
             float4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = TA::frag(As, wm0, i, l31, half, sg);
@@ -339,6 +369,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
 #endif
+            YT_STAMP(2 + sg);
         }
         }
     }
@@ -355,6 +386,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_dma_kernel(const GemmArgs g
             }
         }
     }
+#if YT_GEMM_PROBE
+    if (probing) g_f32_probe[(wave >> 2) * 64 + lane] = ts;
+#endif
 #if YT_GEMM_DMA_SPREAD
     if (!X3) wait_vmcnt<0>();          // the trailing (repeated) requests have landed before this workgroup's LDS is handed on
 #endif
@@ -584,6 +618,9 @@ extern "C" int ytvln_gemm_plan_x3(int M, int N, int K, int transA, int epilogue,
     return 0;
 }
 
+#if YT_GEMM_PROBE
+extern "C" int ytvln_gemm_f32_probe_read(uint32_t* host128) { return hipMemcpyFromSymbol(host128, HIP_SYMBOL(g_f32_probe), 512) == hipSuccess ? 0 : -1; }
+#endif
 extern "C" int64_t ytvln_gemm_workspace_elems(int M, int N, int K, int epilogue) {
     const int splits = std::max(std::max(std::max(std::max(plan_splits(M, N, K, epilogue), plan_gemm(M, N, K, epilogue, true, false, false).splits),
                                                   plan_gemm(M, N, K, epilogue, true, false, true).splits),
