@@ -99,7 +99,12 @@ def test_persistent_gemm_every_tile_right(dev, lib, M, N, K, tb, epi, form, tile
     assert _ctl_zero(dev), "control block not left zero"
     if form == "dp":        # same k order per tile as the launch-per-tile kernel on the same tile shape: bit-identical
         C0 = run(GEMM_SK=0, GEMM_TILE=tile, GEMM_SPLITS=1)
-        assert torch.equal(C, C0), float((C - C0).abs().max())
+        if tile == 0 and epi == 3:
+            # round 6: the 128x128 persistent kernel (the one GEMM kernel with a scratch segment) takes the compiler-counted epilogue loads for
+            # epilogues that read a matrix (gemm_epilogue<..., HAND = false>): same accumulators, the x GELU' product contracted differently
+            assert float((C - C0).abs().max()) <= 1e-6 * float(C0.abs().max()) + 1e-4, float((C - C0).abs().max())
+        else:
+            assert torch.equal(C, C0), float((C - C0).abs().max())
     else:                   # stream-K: fixed-order fix-up -> the same bits every time
         for _ in range(10):
             assert torch.equal(C, run(GEMM_SK=3, GEMM_SK_TILE=tile))

@@ -431,8 +431,13 @@ __device__ __forceinline__ void battn_bwd_dq_body(const BAttnArgs& a, const int 
 //     wait Q(t)    S = Q(t).K^T        (rows = queries of the tile down the registers, column = this lane's key)
 //     wait dO(t)   dP = dO(t).V^T;     p = exp(s - lse), dS = p o (dP o keep - delta)
 //     dK^T += Q(t)^T.dS   -> DMA Q(t+1)          dV^T += dO(t)^T.(P o keep)   -> DMA dO(t+1)
-template <int DP, bool DROP>
+// PART: 0 = dK and dV in one pass (one wave per SIMD at d = 128: 128 accumulator registers beside the K and V fragments); 1 = dV only, 2 = dK only.
+// The two halves recompute S (and share nothing else: dV needs P, dK needs dS = P o (dP - delta)), 40 instead of 32 matrix instructions per
+// tile, but each fits 256 registers, so TWO waves share a SIMD and one wave's ~200-390 vector instructions per tile run under the other's matrix
+// instructions -- the one-pass kernel serialises them (4100 cycles per tile against 1024 of matrix time, profiles/round6 notes in LABNOTES).
+template <int DP, bool DROP, int PART = 0>
 __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int bx, const int h, const int n) {
+    constexpr bool WANT_V = PART != 2, WANT_K = PART != 1;
     using T = BTile<DP>;
     constexpr int NS = DP / 16, NC = DP / 32, PC = T::PC;
     extern __shared__ __attribute__((aligned(16))) char bsmem[];
@@ -455,23 +460,27 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
     qs.issue(0);
     gs.issue(0);
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 Kr[NS], Vr[NS];
+    bf16x8 Kr[NS], Vr[WANT_K ? NS : 1];
     bload_rowfrag<DP>(Kr, a.k, a.ldk, (int64_t)n * a.Tk, kj, a.Tk, col0, half);
-    bload_rowfrag<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, half);
+    if constexpr (WANT_K) bload_rowfrag<DP>(Vr, a.v, a.ldv, (int64_t)n * a.Tk, kj, a.Tk, col0, half);
     __builtin_amdgcn_sched_barrier(0);
     bfill_row(Lrow, a.lse + srow, a.Tq, nqt * 32, 0.f, INFINITY, lane);
-    bfill_row(Drow, a.delta + srow, a.Tq, nqt * 32, 0.f, 0.f, lane);
+    if constexpr (WANT_K) bfill_row(Drow, a.delta + srow, a.Tq, nqt * 32, 0.f, 0.f, lane);
     const float mk = kvalid ? (a.mask ? a.mask[(int64_t)n * a.Tk + kj] : 0.f) : -INFINITY;
     DropKey key = {0, 0, 0, 0};
     uint32_t thr = 0; float ik = 1.f;
     if (DROP) { key = make_drop_key(a.rng, a.site); thr = drop_threshold(a.p_drop); ik = 1.0f / (1.0f - a.p_drop); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    f32x16 accV[NC], accK[NC];
+    f32x16 accV[WANT_V ? NC : 1], accK[WANT_K ? NC : 1];
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < (WANT_V ? NC : 1); ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { accV[c][r] = 0.f; accK[c][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) accV[c][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < (WANT_K ? NC : 1); ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accK[c][r] = 0.f;
 
     // keep bits (see the header): this lane's key is column c = l31 of the block; in the forward's layout that key sat in register rf of half hf
     const int kc = l31, hf = (kc >> 2) & 1, rf = (kc & 3) + 4 * (kc >> 3);
@@ -496,13 +505,16 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
         f32x16 dP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dP[r] = 0.f;
+        if constexpr (WANT_K) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) dP = MFMA_B(T::kc(Gs, l31, half, s), Vr[s], dP);
+            for (int s = 0; s < NS; ++s) dP = MFMA_B(T::kc(Gs, l31, half, s), Vr[s], dP);
+        }
         float Pk[16], dS[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 ls = blds4(Lrow + i0 + 8 * g + 4 * half);
-            const float4 ds = blds4(Drow + i0 + 8 * g + 4 * half);
+            float4 ds = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (WANT_K) ds = blds4(Drow + i0 + 8 * g + 4 * half);
             const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -518,25 +530,29 @@ __device__ __forceinline__ void battn_bwd_dkv_body(const BAttnArgs& a, const int
                 dS[r] = p * (dp - dsv[u]);
             }
         }
-        const bf16x8 Sb[2] = {bpack8(dS), bpack8(dS + 8)};
-        const bf16x8 Pb[2] = {bpack8(Pk), bpack8(Pk + 8)};
+        if constexpr (WANT_K) {
+            const bf16x8 Sb[2] = {bpack8(dS), bpack8(dS + 8)};
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) accK[c] = MFMA_B(T::tr(Qs, lane, mm, c), Sb[mm], accK[c]);          // dK^T += Q^T . dS
+                for (int c = 0; c < NC; ++c) accK[c] = MFMA_B(T::tr(Qs, lane, mm, c), Sb[mm], accK[c]);          // dK^T += Q^T . dS
+        }
         b_reads_done();
         if (more) qs.issue(i0 + 32);
+        if constexpr (WANT_V) {
+            const bf16x8 Pb[2] = {bpack8(Pk), bpack8(Pk + 8)};
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) accV[c] = MFMA_B(T::tr(Gs, lane, mm, c), Pb[mm], accV[c]);          // dV^T += dO^T . (P o keep)
+                for (int c = 0; c < NC; ++c) accV[c] = MFMA_B(T::tr(Gs, lane, mm, c), Pb[mm], accV[c]);          // dV^T += dO^T . (P o keep)
+        }
         b_reads_done();
         if (more) gs.issue(i0 + 32);
     };
     for (int t = 0; t + 1 < nqt; ++t) tile(std::true_type{}, t);
     tile(std::false_type{}, nqt - 1);
-    bstore_rows<DP>(accV, a.dv, a.lddv, (int64_t)n * a.Tk, kj, a.Tk, col0, half, 1.0f);
-    bstore_rows<DP>(accK, a.dk, a.lddk, (int64_t)n * a.Tk, kj, a.Tk, col0, half, a.scale);
+    if constexpr (WANT_V) bstore_rows<DP>(accV, a.dv, a.lddv, (int64_t)n * a.Tk, kj, a.Tk, col0, half, 1.0f);
+    if constexpr (WANT_K) bstore_rows<DP>(accK, a.dk, a.lddk, (int64_t)n * a.Tk, kj, a.Tk, col0, half, a.scale);
 }
 
 // ---- kernel entry points: one launch covers ONE problem or the TWO directions of BertBiAttention (see attention.hip) ---------------------
@@ -558,6 +574,11 @@ __global__ __launch_bounds__(64, 2) void battn_bwd_dq_kernel(const BAttnLaunch b
 #endif
 template <int DP, bool DROP>
 __global__ __launch_bounds__(64, DP == 128 ? BATTN_DKV_WPS : 2) void battn_bwd_dkv_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_bwd_dkv_body<DP, DROP>(a, bx, h, n))); }
+// d = 128 in two passes, two waves per SIMD each (run-time option ATTN_DKV_SPLIT)
+template <int DP, bool DROP>
+__global__ __launch_bounds__(64, 2) void battn_bwd_dv_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_bwd_dkv_body<DP, DROP, 1>(a, bx, h, n))); }
+template <int DP, bool DROP>
+__global__ __launch_bounds__(64, 2) void battn_bwd_dk_kernel(const BAttnLaunch b) { YT_BATTN_DECODE((battn_bwd_dkv_body<DP, DROP, 2>(a, bx, h, n))); }
 #undef YT_BATTN_DECODE
 
 static int bcheck(const char* who, const BAttnArgs& a) {
@@ -646,7 +667,15 @@ static int blaunch_bwd(BAttnLaunch& b, int np, hipStream_t s) {
         const int64_t total = (int64_t)b.nb0 + (np > 1 ? (int64_t)b.gx1 * a0.heads * a0.N : 0);
         YT_REQUIRE(total < (1ll << 31), "attn_bwd_bf16: grid too large");
         const size_t lds = (size_t)2 * 32 * a0.d * 2 + (size_t)2 * cdiv(maxTq, 32) * 32 * sizeof(float);
-        YT_BLAUNCH(battn_bwd_dkv_kernel, lds);
+        if (a0.d == 128 && opt(OPT_ATTN_DKV_SPLIT)) {
+            const size_t lds_v = (size_t)2 * 32 * a0.d * 2 + (size_t)cdiv(maxTq, 32) * 32 * sizeof(float);          // (no delta row in the dV pass)
+            if (drop) { hipLaunchKernelGGL((battn_bwd_dv_kernel<128, true>), dim3((unsigned)total), dim3(64), lds_v, s, b);
+                        hipLaunchKernelGGL((battn_bwd_dk_kernel<128, true>), dim3((unsigned)total), dim3(64), lds, s, b); }
+            else { hipLaunchKernelGGL((battn_bwd_dv_kernel<128, false>), dim3((unsigned)total), dim3(64), lds_v, s, b);
+                   hipLaunchKernelGGL((battn_bwd_dk_kernel<128, false>), dim3((unsigned)total), dim3(64), lds, s, b); }
+        } else {
+            YT_BLAUNCH(battn_bwd_dkv_kernel, lds);
+        }
     }
     YT_LAUNCH_CHECK("attn_bwd_bf16");
     return 0;
