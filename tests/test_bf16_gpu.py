@@ -102,6 +102,38 @@ def test_gemm_bf16_epilogues_splitk_and_padding(dev, lib):
     assert _relmax(C, A2[:, :K].double().t() @ X.double()) < 3e-6 and _relmax(rs, A2[:, :K].double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("form", [1, 2, 3, 4])
+def test_gemm_bf16_main_loop_forms_agree_with_the_shipped_one(dev, lib, form):
+    """The opt-in main loops of the bf16 GEMM (run-time option GEMM_BF16_FORM: DMA issue inside the matrix phases, 32-deep tiles in five-slot rings,
+    four waves of 128x128) accumulate every output element in the same k order as the shipped form (form 3: up to fp32 rounding): bit-identical results on both operand
+    layouts a bf16 C takes, ragged K / M / N included (form 4 hands shapes it has no instantiation for back to the shipped kernel)."""
+    from ytvln import _lib, ops
+    for M, N, K, tb in ((2048, 1024, 1024, 1), (2048, 1024, 1024, 0), (1500, 520, 1088, 1), (4480, 768, 3072, 0), (512, 512, 200, 1)):
+        g = torch.Generator().manual_seed(M + N + K + tb)
+        A = torch.randn(M, K, generator=g).to(dev).to(BF)
+        B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev).to(BF)
+        bias = torch.randn(N, generator=g).to(dev)
+        C2_init = torch.randn(M, N, generator=g).to(dev).to(BF)
+        outs = []
+        for f in (0, form):
+            prev = _lib.set_option("GEMM_BF16_FORM", f)
+            try:
+                C = torch.full((M, N), float("nan"), device=dev, dtype=BF)
+                aux = torch.empty(M, N, device=dev, dtype=BF)
+                _gemm(ops, A, 0, B, tb, C, M, N, K, bias=bias, aux=aux, ldaux=N, epi=1)
+                C2 = C2_init.clone()
+                _gemm(ops, A, 0, B, tb, C2, M, N, K, beta=1.0)
+                torch.cuda.synchronize()
+                outs.append((C, aux, C2))
+            finally:
+                _lib.set_option("GEMM_BF16_FORM", prev)
+        for x, y in zip(*outs):
+            if form == 3:      # 32-deep tiles group the k indices of a matrix instruction differently: same sums up to fp32 rounding, one bf16 ulp at most
+                assert float((x.float() - y.float()).abs().max()) <= 2 ** -7 * float(y.float().abs().max()), (form, M, N, K, tb)
+            else:
+                assert torch.equal(x, y), (form, M, N, K, tb, float((x.float() - y.float()).abs().max()))
+
+
 def _ref_attention(q, k, v, mask, heads, keep=None, p=0.0):
     N, Tq, H = q.shape
     d = H // heads
