@@ -31,6 +31,9 @@
 #include "common.h"
 #include <algorithm>
 
+#ifndef YT_ATTN_SPREAD
+#define YT_ATTN_SPREAD 0        // 1: forward one-wave kernel requests its LDS-DMA pieces between the matrix instructions (round-6 experiment: -0.5 % of the family)
+#endif
 namespace ytvln {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -148,8 +151,12 @@ __device__ __forceinline__ void load_rowfrag_raw(float (&R)[DP / 2], const float
 }
 
 // acc (32x32)[tile row][lane's own row] = Xs-tile (A: rows = lane&31 of the LDS tile, contraction split by half) . Rfrag^T (B: registers)
-template <int DP, int PIPE = 0>
-__device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo) {
+// `fill(slot)`: called once per slot of four (mma_rows: 16 slots at DP = 128) / DP/32 (mma_regs_rows: 16 slots) matrix instructions, between them,
+// order pinned -- the one-wave kernels put the LDS-DMA pieces of the NEXT tile there (YT_ATTN_SPREAD) instead of issuing a whole tile in a burst
+// with the matrix pipe idle.
+struct NoFill { __device__ __forceinline__ void operator()(int) const {} };
+template <int DP, int PIPE = 0, class F = NoFill>
+__device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const float (&R)[DP / 2], const LaneOff& lo, F fill = F{}) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -172,7 +179,8 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
                 acc = MFMA(x[b & 1][u].y, R[4 * gi + 1], acc);
                 acc = MFMA(x[b & 1][u].z, R[4 * gi + 2], acc);
                 acc = MFMA(x[b & 1][u].w, R[4 * gi + 3], acc);
-                if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!std::is_same<F, NoFill>::value) { __builtin_amdgcn_sched_barrier(0); fill(gi); __builtin_amdgcn_sched_barrier(0); }
+                else if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
             }
         }
         return acc;
@@ -192,8 +200,8 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 
 // acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
 //                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
-template <int DP, int PIPE = 0>
-__device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo) {
+template <int DP, int PIPE = 0, class F = NoFill>
+__device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo, F fill = F{}) {
     constexpr int NJ = DP / 32;
     if constexpr (PIPE > 0) {
         // tile rows krow(r, half), r = 0..15, in batches of PIPE reads (see mma_rows)
@@ -216,7 +224,8 @@ __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const floa
                 if (b + 1 < NB) rd(r + HB, v[(b + 1) & 1][u]);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[j] = MFMA(P[r], v[b & 1][u][j], acc[j]);
-                if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!std::is_same<F, NoFill>::value) { __builtin_amdgcn_sched_barrier(0); fill(r); __builtin_amdgcn_sched_barrier(0); }
+                else if (b + 1 < NB) __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else {
@@ -646,6 +655,11 @@ struct W1Stream {
 #pragma unroll
         for (int p = 0; p < PIECES; ++p) roff[p] = RPP * p * ld_ + lrow_ld + gcol[p % NV];
     }
+    // one piece of the tile at row0 (always the clamping form: four more vector instructions than a full tile's piece, branch-free)
+    __device__ __forceinline__ void issue_piece(const int row0, const int p) const {
+        const int off = min(row0 * ld + RPP * p * ld + lrow_ld, lim) + gcol[p % NV];
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (uint32_t)off), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
+    }
     __device__ __forceinline__ void issue(const int row0) const {
         const int sbase = row0 * ld;
         if (row0 + 32 <= nrows) {
@@ -730,11 +744,26 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         constexpr bool FIRST = decltype(FIRST_T)::value, more = decltype(MORE_T)::value;
         const int j0 = t * 32;
         // K(t); V(t) (DP/8 pieces) may still be on its way -- in the first tile also Q, which the matmul needs as well
+#if YT_ATTN_SPREAD
+        // SPREAD: a tile's LDS-DMA pieces are requested between the matrix instructions of the matmul that runs while its buffer is free -- V(t)
+        // under S(t) (the V buffer is free since P.V(t-1); V(0) comes from the prologue), K(t+1) under P.V(t) (the K buffer is free since S(t)) --
+        // two pieces per slot over the first half of the matmul, instead of 16 pieces in a burst behind the matmul that frees the buffer (16 x
+        // ~60 cycles of issue with an idle matrix pipe, twice per tile).  Every wait is vmcnt(0): nothing younger than the tile a matmul needs has
+        // been requested when it starts.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // K(t)
+        constexpr int PCS = DP / 8;
+        auto fill_v = [&](int slot) __attribute__((always_inline)) {
+            if (!FIRST && 2 * slot < PCS) { vs.issue_piece(j0, 2 * slot); vs.issue_piece(j0, 2 * slot + 1); }
+        };
+        const f32x16 S = mma_rows<DP, W1_PIPE>(Ks, Qr, lo, fill_v);
+        lds_reads_done();
+#else
         if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else w1_wait<DP / 8>();
         const f32x16 S = mma_rows<DP, W1_PIPE>(Ks, Qr, lo);
         lds_reads_done();
         if (more) ks.issue(j0 + 32);
+#endif
         if constexpr (FIRST) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -775,12 +804,21 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
                 P[r] = bits >= thr ? P[r] * ik : 0.f;
             }
         }
+#if YT_ATTN_SPREAD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // V(t)
+        auto fill_k = [&](int slot) __attribute__((always_inline)) {          // K(t+1) into Ks, free since S(t)
+            if (more && 2 * slot < PCS) { ks.issue_piece(j0 + 32, 2 * slot); ks.issue_piece(j0 + 32, 2 * slot + 1); }
+        };
+        mma_regs_rows<DP, W1_PIPE>(O, P, Vs, lo, fill_k);
+        lds_reads_done();
+#else
         // V(t); K(t+1), if there is one, may still be on its way
         if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mma_regs_rows<DP, W1_PIPE>(O, P, Vs, lo);
         lds_reads_done();
         if (more) vs.issue(j0 + 32);
+#endif
     };
     if (ntiles == 1) {
         tile(std::true_type{}, std::false_type{}, 0);
