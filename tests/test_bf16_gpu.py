@@ -134,6 +134,35 @@ def test_gemm_bf16_main_loop_forms_agree_with_the_shipped_one(dev, lib, form):
                 assert torch.equal(x, y), (form, M, N, K, tb, float((x.float() - y.float()).abs().max()))
 
 
+def test_gemm_bf16_wide_stores_are_the_same_bits(dev, lib):
+    """GEMM_BF16_WIDE: interior bf16 output tiles leave through an LDS transpose and 16-byte stores instead of 2-byte stores from the accumulator
+    layout -- the same values rounded once: bit-identical C (and saved pre-activation) with the option on and off, for both tile sizes, every
+    epilogue the wide path takes, ragged edges (edge tiles keep the narrow path) and a C with a leading dimension that is not a multiple of 8 (falls back)."""
+    from ytvln import _lib, ops
+    for M, N, K, tb, ldc in ((4480, 768, 768, 1, 768), (2048, 1024, 1024, 0, 1024), (1500, 520, 1088, 1, 520), (300, 200, 64, 1, 200), (512, 256, 128, 1, 260)):
+        g = torch.Generator().manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g).to(dev).to(BF)
+        B = torch.randn((N, K) if tb else (K, N), generator=g).to(dev).to(BF)
+        bias = torch.randn(N, generator=g).to(dev)
+        outs = []
+        for w in (0, 1):
+            prev = _lib.set_option("GEMM_BF16_WIDE", w)
+            try:
+                res = []
+                for epi in (0, 1, 2):
+                    C = torch.full((M, ldc), 3.0, device=dev, dtype=BF)
+                    aux = torch.full((M, N), 5.0, device=dev, dtype=BF) if epi == 1 else None
+                    ops._gemm_bf16(A, K, 0, B, B.stride(0), tb, C, ldc, M, N, K, bias=bias, aux=aux, ldaux=N if aux is not None else 0, epi=epi)
+                    torch.cuda.synchronize()
+                    res += [C] + ([aux] if aux is not None else [])
+                outs.append(res)
+            finally:
+                _lib.set_option("GEMM_BF16_WIDE", prev)
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), (M, N, K, tb, ldc, float((x.float() - y.float()).abs().max()))
+        assert float(outs[1][0][:, N:].float().sub(3.0).abs().max()) == 0 if ldc > N else True          # padding columns untouched
+
+
 def _ref_attention(q, k, v, mask, heads, keep=None, p=0.0):
     N, Tq, H = q.shape
     d = H // heads

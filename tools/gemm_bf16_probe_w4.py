@@ -1,5 +1,7 @@
 """Timeline of the four-wave bf16 GEMM (form 44 = form 4 with stamps): per wave and k-tile the cycles spent in steps 0-2, at the counted wait, at
-the barrier and in step 3."""
+the barrier and in step 3.
+Needs a measurement library: compile youtube-vln_amd/csrc/gemm_bf16_w4.hip with -DYT_W4_MEASURE=1, relink, and run with YTVLN_LIB=<that .so>
+(the shipped library runs form 44 as form 4, without stamps)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "youtube-vln_amd"))
 import numpy as np

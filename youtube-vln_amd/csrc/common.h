@@ -45,9 +45,10 @@ enum Option {
     OPT_GEMM_SK_TILE,        // -1 (default): planner; 3 / 4 forces 256x128 / 256x256 tiles for the persistent kernel
     OPT_GEMM_SK_GROUPS,      // 8 (default): one ticket group per XCD; 1: one group over the whole launch (partial tiles may cross XCDs)
     OPT_GEMM_T224,           // 1 (default): the fp32 planner may take the 224x256 tile (eight waves of 224x32) for single-round launches with a K-contiguous A; 0: never
-    OPT_GEMM_BF16_FORM,      // bf16 GEMM main loop: where the next tiles' LDS-DMA is issued -- 0 in the load phases, 1 A between the matrix instructions, 2 A and B
+    OPT_GEMM_BF16_FORM,      // bf16 GEMM main loop: -1 (default) chosen per launch, 0 eight waves / DMA in the load phases, 1-2 DMA between the matrix instructions, 3 32-deep tiles, 4 four waves of 128x128
     OPT_GEMM_STAGGER,        // bf16 GEMM, launches of >= 3 rounds of 256x256 tiles: half of the first round starts this many percent of a tile's main loop late (0 = off)
     OPT_ATTN_DKV_SPLIT,      // bf16 attention, d = 128: 1 = dK and dV in two passes with two waves per SIMD each, 0 = one pass with one wave per SIMD
+    OPT_GEMM_BF16_WIDE,      // 1: bf16 GEMM outputs leave through LDS-transposed 16-byte stores where the epilogue reads no matrix; 0: 2-byte stores
     OPT_COUNT
 };
 int opt(int id);

@@ -49,6 +49,7 @@ struct BfArgs {
     int kvalidA, kvalidB;        // contraction indices below these are readable: K -- or, for a contraction-contiguous A with zero padding behind K, K rounded up to 8
     float* asum; float* asum_ws; // optional: asum[m] = sum_k A[k][m] of a k-major A
     int stagger_ticks;           // > 0: every second octet of the launch's first round of workgroups starts this many 100 MHz ticks late (see the kernel)
+    int wide_stores;             // 1: bf16 C through the LDS-transposed 16-byte stores where the epilogue allows (run-time option GEMM_BF16_WIDE)
     uint32_t* probe; int probe_block, probe_mask;      // diagnostics (ytvln_gemm_bf16_probe): phase time stamps of waves 0 and 4 of this workgroup
 };
 
@@ -323,6 +324,92 @@ __device__ __forceinline__ void bf_epilogue(const BfArgs& g, f32x16 (&acc)[TM][T
             break;
     }
 #undef YT_BF_EPI
+}
+
+// ---- wide stores of a bf16 C ----------------------------------------------------------------------------------------------------------
+// The matrix instruction leaves a lane with 4 consecutive ROWS of one column per register group, i.e. 2-byte stores (128 per wave on a 64x128
+// sub-tile; measured: the store tail is a third of a tile's fixed cost).  For tiles inside the matrix and epilogues that read no matrix (plain /
+// bias, ReLU, GELU with or without the saved pre-activation) each wave instead transposes one 32-row block at a time through its own slice of the
+// -- by then idle -- LDS: packed bf16 column segments written with ds_write_b64 (column stride 72 bytes: conflict-free), read back by
+// ds_read_b64_tr_b16 as 8 consecutive columns of a row, stored 16 bytes per lane: 2 TN store instructions per block instead of 16 TN.
+constexpr int BF_TCS = 72;          // bytes per column of the transposing image: 32 rows x 2 B + 8
+template <int TN>
+__device__ __forceinline__ constexpr int bf_wide_bytes() { return 32 * TN * BF_TCS; }          // LDS per wave
+// MODE 0: v + bias (the plain product / the saved pre-activation), 1: relu, 2: gelu.  Write half: one 32-row block into its image at tb.
+template <int TN> struct BfBlk { f32x16 v[TN]; };          // the accumulators of one 32-row block of a wave's tile
+template <int TN, int MODE>
+__device__ __forceinline__ void bf_wide_write(const BfBlk<TN>& blkw, const float (&bv)[TN], char* __restrict__ tb, int lane) {
+    const f32x16 (&blk)[TN] = blkw.v;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v = blk[j][4 * q + u] + bv[j];
+                if (MODE == 1) v = fmaxf(v, 0.f);
+                if (MODE == 2) v = gelu_erf(v);
+                h[u] = f2bf(v);
+            }
+            *reinterpret_cast<uint2*>(tb + (32 * j + l31) * BF_TCS + (8 * q + 4 * half) * 2) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        }
+}
+// Read half: lane (group gq = lane >> 4, jj = lane & 15) ends up with row 16 rh + jj, columns 32 cb + 8 gq .. + 7; for the transposing read it SUPPLIES
+// the address of T[column 32 cb + 8 gq + 4 u + rr][rows 16 rh + 4 c4 ..] (rr = jj >> 2, c4 = jj & 3)
+template <int TN>
+__device__ __forceinline__ void bf_wide_store(const char* __restrict__ tb, bf16_t* __restrict__ dst, int64_t ld, int row0, int col0, int lane) {
+    const int gq = lane >> 4, jj = lane & 15, rr = jj >> 2, c4 = jj & 3;
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+        for (int cb = 0; cb < TN; ++cb) {
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const char* p0 = tb + (32 * cb + 8 * gq + rr) * BF_TCS + (16 * rh + 4 * c4) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_ptr_t)(const_cast<char*>(p0)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_ptr_t)(const_cast<char*>(p0 + 4 * BF_TCS)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<s16x8*>(dst + (int64_t)(row0 + 16 * rh + jj) * ld + col0 + 32 * cb + 8 * gq) = v;
+        }
+}
+// may this wave's TM x TN block grid at (row0, col0) take the wide path?  (wave-uniform)
+template <int TM, int TN>
+__device__ __forceinline__ bool bf_wide_ok(const BfArgs& g, int row0, int col0) {
+    return g.wide_stores && g.beta == 0.f && g.epilogue <= YTVLN_EPI_RELU && g.splits == 1 && row0 + 32 * TM <= g.M && col0 + 32 * TN <= g.N &&
+           (g.ldc % 8) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+           (g.epilogue != YTVLN_EPI_GELU || g.aux == nullptr || ((g.ldaux % 8) == 0 && (reinterpret_cast<uintptr_t>(g.aux) & 15) == 0));
+}
+// The whole TM x TN block grid of a wave, EVERY block in its own LDS image (TM x bf_wide_bytes<TN>() per wave: 147 KB per workgroup on the
+// 256x256 tiles), so that the LDS round trip is paid once per pass and not once per block: all blocks written, one wait, all blocks stored.
+// `get(i)` hands out block i's accumulators (a reference, or a copy read out of the accumulation registers).
+template <int TM, int TN, int MODE, class Get>
+__device__ __forceinline__ void bf_wide_pass(Get&& get, const float (&bv)[TN], char* __restrict__ tb, bf16_t* __restrict__ dst, int64_t ld, int row0, int col0,
+                                             int lane) {
+    static_for<TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        bf_wide_write<TN, MODE>(get(ic), bv, tb + i * bf_wide_bytes<TN>(), lane);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bf_wide_store<TN>(tb + i * bf_wide_bytes<TN>(), dst, ld, row0 + 32 * i, col0, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads have returned before a next pass overwrites the images
+}
+template <int TM, int TN, class Get>
+__device__ __forceinline__ void bf_wide_tile(const BfArgs& g, Get&& get, char* __restrict__ tb, int row0, int col0, int lane) {
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = g.bias ? g.bias[col0 + 32 * j + (lane & 31)] : 0.f;
+    bf16_t* const Cp = reinterpret_cast<bf16_t*>(g.C);
+    if (g.epilogue == YTVLN_EPI_GELU) {
+        if (g.aux) bf_wide_pass<TM, TN, 0>(get, bv, tb, g.aux, g.ldaux, row0, col0, lane);
+        bf_wide_pass<TM, TN, 2>(get, bv, tb, Cp, g.ldc, row0, col0, lane);
+    } else if (g.epilogue == YTVLN_EPI_RELU) {
+        bf_wide_pass<TM, TN, 1>(get, bv, tb, Cp, g.ldc, row0, col0, lane);
+    } else {
+        bf_wide_pass<TM, TN, 0>(get, bv, tb, Cp, g.ldc, row0, col0, lane);
+    }
 }
 
 // workgroup id -> (tile row, tile column, split): the XCD-aware orders of gemm.hip (each XCD gets a contiguous run of the group-major tile
@@ -634,6 +721,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void gemm_bf16_kernel(const BfArgs g)
             }
         }
     }
+    if constexpr (std::is_same<CT, bf16_t>::value) {
+        if (bf_wide_ok<TM, TN>(g, m0 + wm0, n0 + wn0)) {          // (behind the loop's last barrier nobody reads the operand rings any more)
+            char* const tb = smem + wave * (TM * bf_wide_bytes<TN>());
+            bf_wide_tile<TM, TN>(g, [&](auto ic) {
+                BfBlk<TN> b;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b.v[j] = acc[decltype(ic)::value][j];
+                return b;
+            }, tb, m0 + wm0, n0 + wn0, lane);
+            return;
+        }
+    }
     bf_epilogue<TM, TN, CT>(g, acc, m0 + wm0, n0 + wn0, l31, half, tc.split);
 }
 
@@ -677,7 +776,12 @@ template <typename CT>
 static void bf_launch(const BfArgs& g0, int big, int transA, int transB, hipStream_t s) {
     BfArgs g = g0;
     g.probe = nullptr; g.probe_block = 0; g.probe_mask = 0;
-    const int form = opt(OPT_GEMM_BF16_FORM);
+    int form = opt(OPT_GEMM_BF16_FORM);
+    // -1: per launch -- the four-wave 128x128 kernel from K = 2048 up (its shorter k-tile outweighs its ~1.7 us of extra fixed cost per round there:
+    // -3 ... -6 % in isolation, profiles/round6_gemm_bf16_wide_ab.log), the eight-wave kernel below.  NOT the default: in the cfg-5 step the choice
+    // measured -0.9 % (profiles/round6_cfg5_form_auto_ab.log: beside the other stream's kernels, and with the beta = 1 input-gradient launches on
+    // form 4's 2-byte store path)
+    if (form < 0) form = (big && !transA && std::is_same<CT, bf16_t>::value && g.K >= 2048 && g.K % KT == 0 && g.splits == 1) ? 4 : 0;
     if (form == 44) { g.probe = g_bf_probe; g.probe_block = g_bf_probe_block; g.probe_mask = g_bf_probe_mask; }
     if constexpr (std::is_same<CT, bf16_t>::value) {
         if (g_bf_probe && big && !transA && transB && form == 0) {          // diagnostics: the forward layout of the 256x256 tile with phase stamps
@@ -877,6 +981,10 @@ extern "C" int ytvln_gemm_bf16(const uint16_t* A, int64_t lda, int transA, const
     g.M = M; g.N = N; g.K = K; g.epilogue = epilogue; g.beta = beta;
     g.splits = 1; g.kchunk = (int)cdiv(std::max(K, 1), KT) * KT; g.ws = nullptr; g.asum = nullptr; g.asum_ws = nullptr;
     g.mnA = M; g.mnB = N; g.kvalidA = K; g.kvalidB = K; g.stagger_ticks = 0;
+    // wide stores: 1 always where legal, 0 (default) never on the eight-wave kernel (the four-wave form always uses them), -1 where they measured ahead on the eight-wave
+    // kernel: outputs that dwarf the contraction (the 30522-wide decoder: -5 %); on the 768 ... 3072-wide projections the LDS round trip costs
+    // more than the 2-byte stores it replaces (+1 ... +10 %)
+    { const int w = opt(OPT_GEMM_BF16_WIDE); g.wide_stores = w >= 0 ? w : (N >= 8192 && N >= 8 * K); }
     // Fast-path legality: 16-byte aligned operands whose rows start on 16-byte boundaries, and whole 16-byte granules:
     //   contraction-contiguous operand: K % 8 == 0 -- or, for A only, readable ZERO padding behind K up to lda (YTVLN_GEMM_A_ZERO_PADDED: the
     //     30522- and 1601-wide logit gradients as the A operand of the input-gradient GEMM);

@@ -23,6 +23,10 @@
 #define YT_BF16_SHARED_ONLY 1
 #include "gemm_bf16.hip"
 
+#ifndef YT_W4_MEASURE
+#define YT_W4_MEASURE 0
+#endif
+
 namespace ytvln {
 
 template <int N>
@@ -192,17 +196,42 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const BfArgs g) {
     // The epilogue, one 32-row block of the wave's tile at a time: the accumulators live in the accumulation half of the register file and
     // every epilogue value has to pass through the other half.  Left to itself hipcc moves all 256 across in front of the epilogue switch and
     // spills 60-100 of them (26 us of fixed cost per round, measured); here each block's 64 values are read out explicitly just before use.
-    static_for<TM>([&](auto ic) {
+    // wide stores of a bf16 C through this wave's slice of the idle LDS where the epilogue allows (gemm_bf16.hip: bf_wide_*)
+    constexpr bool C16 = std::is_same<CT, bf16_t>::value;
+    BfArgs gw = g; gw.wide_stores = 1;          // (this form always takes the wide path where it is legal: its lone wave per SIMD is store-issue bound)
+    const bool wide = C16 && bf_wide_ok<TM, TN>(gw, m0 + wm0, n0 + wn0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the operand rings before any wave reuses LDS (`wide` differs between waves
+                                                             // of an edge tile, so the barrier is unconditional)
+    // block i's 64 accumulators, read out of the accumulation registers just before use (left to itself hipcc moves all 256 across in front of the
+    // epilogue switch and spills 60-100 of them: 26 us of fixed cost per round, measured)
+    using Blk = BfBlk<TN>;
+    auto take = [&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        f32x16 blk[1][TN];
+        Blk b;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float x;
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[i][j][r]));
-                blk[0][j][r] = x;
+                b.v[j][r] = x;
             }
+        return b;
+    };
+    if constexpr (C16) {
+        if (wide) {
+            char* const tb = smem + wave * (TM * bf_wide_bytes<TN>());
+            bf_wide_tile<TM, TN>(g, [&](auto ic) { return take(ic); }, tb, m0 + wm0, n0 + wn0, lane);
+            return;
+        }
+    }
+    static_for<TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        Blk b = take(ic);
+        f32x16 blk[1][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) blk[0][j] = b.v[j];
         bf_epilogue<1, TN, CT>(g, blk, m0 + wm0 + 32 * i, n0 + wn0, l31, half, tc.split);
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -213,11 +242,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const BfArgs g) {
 bool bf_launch_w4(const BfArgs& g, int transA, int transB, hipStream_t s) {
     if (transA || g.K % KT != 0 || g.splits != 1) return false;
     const dim3 grid((unsigned)(g.ntiles * g.splits)), blk(256);
-    const int abl = opt(OPT_GEMM_BF16_FORM) - 40;          // 41 / 42 / 43: the ablation builds (forward layout only)
+#if YT_W4_MEASURE
+    // 41 / 42 / 43: the ablation builds, 44: the stamped one (forward layout only).  Compiled only with -DYT_W4_MEASURE=1 (they quadruple this
+    // file's 4-minute compile and 41-43 give wrong results by construction, so the shipped library does not carry them; there 41-44 run as form 4).
+    const int abl = opt(OPT_GEMM_BF16_FORM) - 40;
     if (transB && abl == 1) { hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, true, bf16_t, 1>), grid, blk, 0, s, g); return true; }
     if (transB && abl == 2) { hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, true, bf16_t, 2>), grid, blk, 0, s, g); return true; }
     if (transB && abl == 4) { hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, true, bf16_t, 0, true>), grid, blk, 0, s, g); return true; }
     if (transB && abl == 3) { hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, true, bf16_t, 3>), grid, blk, 0, s, g); return true; }
+#endif
     if (transB) hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, true, bf16_t>), grid, blk, 0, s, g);
     else hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, false, bf16_t>), grid, blk, 0, s, g);
     return true;

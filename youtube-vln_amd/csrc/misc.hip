@@ -25,7 +25,7 @@ struct OptionEntry { const char* name; int dflt; };
 static const OptionEntry kOptions[OPT_COUNT] = {
     {"ATTN_W1", 7}, {"ATTN_W1_DKV_ANY", 0}, {"ATTN_DSPLIT", 1}, {"GEMM_TILE", -1}, {"GEMM_SPLITS", -1}, {"GEMM_SPLIT_MAP", 1}, {"GEMM_GENERIC", 0},
     {"GEMM_SW", 0}, {"GEMM_SK", 0}, {"GEMM_SK_TILE", -1}, {"GEMM_SK_GROUPS", 8}, {"GEMM_T224", 1},
-    {"GEMM_BF16_FORM", 0}, {"GEMM_STAGGER", 0}, {"ATTN_DKV_SPLIT", 0},
+    {"GEMM_BF16_FORM", 0}, {"GEMM_STAGGER", 0}, {"ATTN_DKV_SPLIT", 0}, {"GEMM_BF16_WIDE", 0},
 };
 static std::atomic<int> g_opt_value[OPT_COUNT];
 static std::atomic<int> g_opt_set[OPT_COUNT];          // 0: not read yet, 1: holds a value
