@@ -11,7 +11,8 @@ from ytvln import ops
 dev = torch.device("cuda", 0)
 N = int(os.environ.get("PAIRS_N", "56"))            # PAIRS_N=224 REGIONS=576: the cfg-5 shapes
 RG = int(os.environ.get("REGIONS", "288"))
-cases = [("img self", 8, 128, RG, RG), ("co t->v", 8, 128, 80, RG), ("co v->t", 8, 128, RG, 80), ("txt self", 12, 64, 80, 80)]
+TX = int(os.environ.get("TEXT", "80"))             # TEXT=64|96: the 32-row neighbours of the 80-token text (what a 16-row tail could save at most)
+cases = [("img self", 8, 128, RG, RG), ("co t->v", 8, 128, TX, RG), ("co v->t", 8, 128, RG, TX), ("txt self", 12, 64, TX, TX)]
 only = os.environ.get("CASES")          # e.g. CASES="co" -> only the BertBiAttention shapes
 if only:
     cases = [c for c in cases if c[0].startswith(only)]
@@ -46,7 +47,7 @@ for name, h, d, Tq, Tk in cases:
 
 # both BertBiAttention directions in ONE launch per kernel (ytvln_attn_fwd_pair / ytvln_attn_bwd_pair), as CoAttentionFn runs them
 if not only or only.startswith("co"):
-    h, d, T, R = 8, 128, 80, RG
+    h, d, T, R = 8, 128, TX, RG
     Hb = h * d
     q1, kv1 = torch.randn(N * R, Hb, device=dev).to(DT), torch.randn(N * R, 2 * Hb, device=dev).to(DT)
     q2, kv2 = torch.randn(N * T, Hb, device=dev).to(DT), torch.randn(N * T, 2 * Hb, device=dev).to(DT)

@@ -200,12 +200,17 @@ __device__ __forceinline__ f32x16 mma_rows(const float* __restrict__ Xs, const f
 
 // acc[j][own row (registers)][column (DP/32)*lane + j] += P (A: own registers, contraction over the 32 tile rows in krow order)
 //                                                          . Xs-tile (B: DP/32 consecutive columns of tile row krow(r, half))
-template <int DP, int PIPE = 0, class F = NoFill>
+// NR = 8: only tile rows 0..15 (krow(r, half), r < 8, are exactly those) -- the last tile of a sequence whose length is 16 mod 32 (the 80-token
+// text: 2.5 tiles) holds nothing past row 15 that is not multiplied by an exact zero (p = 0 behind a -inf mask / a +inf lse), so the matmuls
+// that CONTRACT over the tile rows drop that half: same bits, half the matrix instructions and LDS reads of the tail.  (The matmuls whose OUTPUT
+// rows are the tile rows cannot: a 32x32 instruction produces all 32; see DESIGN section 7 for what a 16x16x4 tail would add and cost.)
+template <int DP, int PIPE = 0, class F = NoFill, int NR = 16>
 __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const float (&P)[16], const float* __restrict__ Xs, const LaneOff& lo, F fill = F{}) {
     constexpr int NJ = DP / 32;
+    static_assert(NR == 16 || NR == 8, "whole tile or its first 16 rows");
     if constexpr (PIPE > 0) {
-        // tile rows krow(r, half), r = 0..15, in batches of PIPE reads (see mma_rows)
-        constexpr int HB = PIPE > 16 ? 16 : PIPE, NB = 16 / HB;
+        // tile rows krow(r, half), r = 0..NR-1, in batches of PIPE reads (see mma_rows)
+        constexpr int HB = PIPE > NR ? NR : PIPE, NB = NR / HB;
         auto rd = [&](int r, float (&v)[NJ]) {
             const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
             if constexpr (NJ == 4) { const float4 t = lds4(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
@@ -230,7 +235,7 @@ __device__ __forceinline__ void mma_regs_rows(f32x16 (&acc)[DP / 32], const floa
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {         // tile row krow(r, half)
+        for (int r = 0; r < NR; ++r) {         // tile row krow(r, half)
             const float* p = Xs + lo.brow[r & 3] + 8 * (r >> 2) * DP;
             if constexpr (NJ == 4) {
                 const float4 v = lds4(p);
@@ -631,6 +636,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
 template <int N>
 __device__ __forceinline__ void w1_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifndef YT_ATTN_SHORT_TILE
+#define YT_ATTN_SHORT_TILE 1          // 0: measurement build without the 16-row last tile (see mma_regs_rows).  d = 128 only: at d = 64 (text self-attention)
+                                      // the same branch measured +2.5 % on a ~26 us kernel (profiles/round6_attn_short_tile_ab.log), at d = 128 -1.1 % on the co-attention pair
+#endif
 #ifndef W1_PIPE
 #define W1_PIPE 8          // LDS fragment reads in flight ahead of the matrix instructions of the one-wave kernels (mma_rows / mma_regs_rows); measured: 4 the same within 1 %, 16 slower (backward 703 -> 738 us: registers)
 #endif
@@ -815,7 +824,8 @@ __device__ __forceinline__ void attn_fwd_w1_body(const AttnArgs& a, const int bx
         // V(t); K(t+1), if there is one, may still be on its way
         if (more) w1_wait<DP / 8>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mma_regs_rows<DP, W1_PIPE>(O, P, Vs, lo);
+        if (YT_ATTN_SHORT_TILE && DP == 128 && !more && a.Tk - j0 <= 16) mma_regs_rows<DP, W1_PIPE, NoFill, 8>(O, P, Vs, lo);          // (wave-uniform; only the last tile can be short)
+        else mma_regs_rows<DP, W1_PIPE>(O, P, Vs, lo);
         lds_reads_done();
         if (more) vs.issue(j0 + 32);
 #endif
@@ -960,7 +970,8 @@ __device__ __forceinline__ void attn_bwd_dq_w1_body(const AttnArgs& a, const int
                 dS[r] = p * (dp - dl);
             }
         }
-        mma_regs_rows<DP, W1_PIPE>(dQ, dS, Ks, lo);
+        if (YT_ATTN_SHORT_TILE && DP == 128 && a.Tk - j0 <= 16) mma_regs_rows<DP, W1_PIPE, NoFill, 8>(dQ, dS, Ks, lo);          // a 16-row last tile: see mma_regs_rows
+        else mma_regs_rows<DP, W1_PIPE>(dQ, dS, Ks, lo);
         lds_reads_done();
         if (more) ktile(j0 + 32);
     };
@@ -1175,10 +1186,13 @@ __device__ __forceinline__ void attn_bwd_dkv_w1_body(const AttnArgs& a, const in
                 dS[r] = p * (dp - dsv[u]);
             }
         }
-        mma_regs_rows<DP, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
+        const bool short_tile = YT_ATTN_SHORT_TILE && DP == 128 && !more && a.Tq - i0 <= 16;          // a 16-row last tile: see mma_regs_rows
+        if (short_tile) mma_regs_rows<DP, W1_PIPE, NoFill, 8>(accK, dS, Qs, lo);
+        else mma_regs_rows<DP, W1_PIPE>(accK, dS, Qs, lo);          // dK += dS^T . Q
         lds_reads_done();
         if (more) qtile(i0 + 32);
-        mma_regs_rows<DP, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
+        if (short_tile) mma_regs_rows<DP, W1_PIPE, NoFill, 8>(accV, Pk, Gs, lo);
+        else mma_regs_rows<DP, W1_PIPE>(accV, Pk, Gs, lo);          // dV += (P o keep)^T . dO
         lds_reads_done();
         if (more) gtile(i0 + 32);
     };
