@@ -416,6 +416,9 @@ void launch_x3(int bm, int bn, const GemmArgs& g, int transA, int transB, unsign
 }  // namespace ytvln
 #else       // ---- everything below belongs to the main translation unit -------------------------------------------------------------
 
+#ifndef YT_SPLITK_REDUCE_UNROLL
+#define YT_SPLITK_REDUCE_UNROLL 4          // partial tiles loaded per batch (1 = the round 1-5 loop)
+#endif
 // C = sum_s ws[s] (+ bias) (+ beta*C), fixed summation order -> deterministic.  One thread per 4 consecutive columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
                                                             const float* __restrict__ bias, int M, int N, int splits, float beta,
@@ -435,7 +438,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const int64_t i = (int64_t)row * N + col;
         if (vec) {
             float4 acc = *reinterpret_cast<const float4*>(ws + i);
-            for (int s = 1; s < splits; ++s) {
+            // (the partial tiles are loaded YT_SPLITK_REDUCE_UNROLL at a time and added in split order: the same sum, but that many 16-byte loads in flight per lane
+            // instead of the one or two a run-time trip count leaves -- 1024 blocks of four waves are otherwise short of the ~40 KB per CU that
+            // 5 TB/s at ~2 us of latency needs)
+            int s = 1;
+            for (; s + YT_SPLITK_REDUCE_UNROLL <= splits; s += YT_SPLITK_REDUCE_UNROLL) {
+                float4 v[YT_SPLITK_REDUCE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < YT_SPLITK_REDUCE_UNROLL; ++u) v[u] = *reinterpret_cast<const float4*>(ws + (int64_t)(s + u) * total + i);
+#pragma unroll
+                for (int u = 0; u < YT_SPLITK_REDUCE_UNROLL; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; s < splits; ++s) {
                 const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * total + i);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
