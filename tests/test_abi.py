@@ -120,6 +120,8 @@ def test_gemm_launch_planner_host_logic():
     assert plan(4480, 768, 3072) == (160, 256, 3)              # 84 tiles of 160x256 x 3 splits = 252 workgroups in one round (128x128 unsplit until round 5)
     assert plan(4480, 3072, 768) == (224, 256, 1)              # 4480 = 20 x 224: 240 whole tiles in one round (216 of 256x256, 12 of them half empty)
     assert plan(4480, 2304, 768) == (160, 256, 1)              # 4480 = 28 x 160: 252 whole tiles in one round
+    # long contractions (round 6): one round of 160- / 224-row tiles instead of six splits of 128x128 -- the LM decoder's input gradient and its kin
+    assert plan(4480, 768, 30528) == (160, 256, 3) and plan(4480, 768, 8192) == (160, 256, 3) and plan(4480, 1024, 8192) == (224, 256, 3)
     assert plan(4480, 30528, 768)[0] != 224                    # many rounds: no gain from the 224-row tile (measured), stays on the well-trodden ones
     assert plan(4480, 1024, 768)[:2] == (64, 64)               # 280 128x128 tiles = 55 % of two waves -> small tiles
     # weight gradients (M-contiguous A): few tiles, long contraction -> deterministic split-K; since round 2 the 256x256 tile competes there

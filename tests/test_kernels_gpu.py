@@ -564,6 +564,32 @@ def test_gemm_zero_padded_tails(dev, lib):
         assert rel_l2(a.grad, r.grad) < 2e-5, nme
 
 
+def test_gemm_decoder_input_gradient_full_size_on_the_long_k_plan(dev, lib):
+    """dX of the 30522-wide LM decoder at its cfg-2 size (vilbert.py:906 backward): 4480 x 768 x 30522 with A's K tail zero padded.  Since round 6
+    the planner gives this launch ONE round of 160x256 tiles with three splits (tests/test_abi.py pins the plan); every 128x128 block of the
+    result against fp64, and the launch is bit-reproducible."""
+    import ctypes
+    from ytvln import ops, _lib
+    from ytvln._lib import GEMM_A_ZERO_PADDED
+    M, V, H = 4480, 30522, 768
+    tm, tn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert _lib.load().ytvln_gemm_plan(M, H, (V + 31) // 32 * 32, 0, 0, ctypes.byref(tm), ctypes.byref(tn), ctypes.byref(sp)) == 0
+    assert (tm.value, tn.value, sp.value) == (160, 256, 3)
+    ld = (V + 31) // 32 * 32
+    dl = torch.zeros(M, ld, device=dev)
+    dl[:, :V] = rnd(dev, M, V, seed=1) * 0.1
+    E = rnd(dev, V, H, seed=2)
+    ref = dl[:, :V].double() @ E.double()
+    dx = torch.empty(M, H, device=dev)
+    ops._gemm(dl, ld, 0, E, H, 0, dx, H, M, H, V, flags=GEMM_A_ZERO_PADDED)
+    err = (dx.double() - ref).abs()
+    blocks = err.view(M // 128, 128, H // 128, 128).amax(dim=(1, 3))          # (the bar of tests/test_gemm_sk_gpu.py for the same product)
+    assert float(blocks.max()) < 4e-6 * math.sqrt(V) + 1e-6, float(blocks.max())
+    dx2 = torch.empty(M, H, device=dev)
+    ops._gemm(dl, ld, 0, E, H, 0, dx2, H, M, H, V, flags=GEMM_A_ZERO_PADDED)
+    assert torch.equal(dx, dx2)
+
+
 @pytest.mark.parametrize("M,N,K,ta,tb,epi", [
     (384, 256, 256, 0, 1, 0), (300, 200, 96, 0, 0, 0), (300, 200, 96, 1, 0, 0), (260, 132, 64, 1, 1, 0), (512, 384, 256, 0, 1, 1),
     (128, 256, 4096, 1, 0, 0), (1000, 520, 160, 0, 1, 3),

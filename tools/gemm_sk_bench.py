@@ -14,16 +14,21 @@ DW = [(1024, 1024, 16128, 2), (3072, 1024, 16128, 2), (2048, 1024, 16128, 2), (7
 CO = [(4480, 768, 2048, 0), (4480, 2048, 768, 1), (4480, 1024, 768, 1), (4480, 1024, 768, 0), (4480, 768, 1024, 1), (4480, 768, 1024, 0),
       (4480, 768, 768, 0), (16128, 1601, 1024, 1), (16128, 1024, 1601, 0)]      # co-attention text side, the 1601-way image head
 which = os.environ.get("SHAPES", "all")
-shapes = {"img": IMG, "text": TEXT, "dw": DW, "co": CO, "textco": TEXT + CO, "all": IMG + TEXT, "all3": IMG + TEXT + DW}[which]
+if os.environ.get("SHAPE"):          # SHAPE=M,N,K,tb[;M,N,K,tb...]: ad-hoc shapes (tb = 2: the weight-gradient layout)
+    which = "custom"
+CUSTOM = [tuple(int(x) for x in t.split(",")) for t in os.environ.get("SHAPE", "").split(";") if t]
+shapes = {"custom": CUSTOM, "img": IMG, "text": TEXT, "dw": DW, "co": CO, "textco": TEXT + CO, "all": IMG + TEXT, "all3": IMG + TEXT + DW}[which]
 ITERS = int(os.environ.get("ITERS", "20"))
 CONFIGS = [("old", dict(GEMM_SK=0)), ("dp4", dict(GEMM_SK=2, GEMM_SK_TILE=4)), ("sk4", dict(GEMM_SK=3, GEMM_SK_TILE=4)),
            ("dp3", dict(GEMM_SK=2, GEMM_SK_TILE=3)), ("sk3", dict(GEMM_SK=3, GEMM_SK_TILE=3)),
            ("sw4", dict(GEMM_SK=0, GEMM_TILE=4, GEMM_SW=1)), ("sw3", dict(GEMM_SK=0, GEMM_TILE=3, GEMM_SW=1)), ("old3", dict(GEMM_SK=0, GEMM_TILE=3)),
            ("old4", dict(GEMM_SK=0, GEMM_TILE=4)), ("old0", dict(GEMM_SK=0, GEMM_TILE=0)), ("sk0", dict(GEMM_SK=3, GEMM_SK_TILE=0)),
            ("dp0", dict(GEMM_SK=2, GEMM_SK_TILE=0)), ("sk0g1", dict(GEMM_SK=3, GEMM_SK_TILE=0, GEMM_SK_GROUPS=1))]
+# TSn_m: tile n forced with m splits (planner experiments), e.g. CONFIGS=old,TS5_4
+CONFIGS += [(f"TS{t}_{sp}", dict(GEMM_SK=0, GEMM_TILE=t, GEMM_SPLITS=sp)) for t in (0, 4, 5, 6) for sp in (1, 2, 3, 4, 5, 6, 8)]
 if os.environ.get("CONFIGS"):
     CONFIGS = [c for c in CONFIGS if c[0] in os.environ["CONFIGS"].split(",")]
-DEFAULTS = dict(GEMM_SK=0, GEMM_SK_TILE=-1, GEMM_SK_GROUPS=8, GEMM_TILE=-1, GEMM_SW=0)
+DEFAULTS = dict(GEMM_SK=0, GEMM_SK_TILE=-1, GEMM_SK_GROUPS=8, GEMM_TILE=-1, GEMM_SW=0, GEMM_SPLITS=-1)
 
 
 def setopts(d):

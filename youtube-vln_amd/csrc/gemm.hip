@@ -541,8 +541,10 @@ static Plan plan_gemm(int M, int N, int K, int epilogue, bool big_ok = false, bo
         const int smax = ((tile == 0 || tile >= 5 || (tile == 4 && (x3 || ta))) && epilogue == YTVLN_EPI_NONE) ? (int)std::min<int64_t>(16, K / 256) : 1;
         for (int sp = 1; sp <= std::max(1, smax); ++sp) {
             if (force_sp >= 0 && sp != std::max(1, std::min(force_sp, std::max(1, smax)))) continue;
-            // (long contractions: not measured, left on the old plans; short ones lose: 4480x1024x768 x 3 splits of 256 measured 76 us against 72.5)
-            if (tile >= 5 && sp > 1 && force_tile < 0 && (ntile * sp > sk_num_cus() || K > 4096 || K / sp < 512)) break;
+            // (short contractions lose: 4480x1024x768 x 3 splits of 256 measured 76 us against 72.5.  Long ones -- round 6, profiles/round6_long_k_plans.log:
+            // one round of 160- / 224-row tiles beats six splits of 128x128 wherever it exists, 4480x768x30528 (the LM decoder's input gradient)
+            // 1915 -> 1501 us, 4480x768x8192 526 -> 418, 4480x1024x8192 639 -> 571 -- so the K <= 4096 limit of round 5 is gone)
+            if (tile >= 5 && sp > 1 && force_tile < 0 && (ntile * sp > sk_num_cus() || K / sp < 512)) break;
             const double t = plan_cost(M, N, K, tile, sp, epilogue, x3, ta);
             // near-ties go to the earlier candidate (fewer splits, the well-trodden 128x128 path); the 256-row tiles only need 0.5 %
             if (t < best_t * (tile >= 3 ? 0.995 : 0.98)) { best_t = t; best = {tile, sp}; }
