@@ -137,7 +137,7 @@ def test_gemm_bf16_main_loop_forms_agree_with_the_shipped_one(dev, lib, form):
 def test_gemm_bf16_wide_stores_are_the_same_bits(dev, lib):
     """GEMM_BF16_WIDE: interior bf16 output tiles leave through an LDS transpose and 16-byte stores instead of 2-byte stores from the accumulator
     layout -- the same values rounded once: bit-identical C (and saved pre-activation) with the option on and off, for both tile sizes, every
-    epilogue the wide path takes, ragged edges (edge tiles keep the narrow path) and a C with a leading dimension that is not a multiple of 8 (falls back)."""
+    epilogue (the GELU one keeps the 2-byte path under either setting), ragged edges (edge tiles keep the narrow path) and a C with a leading dimension that is not a multiple of 8 (falls back)."""
     from ytvln import _lib, ops
     for M, N, K, tb, ldc in ((4480, 768, 768, 1, 768), (2048, 1024, 1024, 0, 1024), (1500, 520, 1088, 1, 520), (300, 200, 64, 1, 200), (512, 256, 128, 1, 260)):
         g = torch.Generator().manual_seed(M + N + K)

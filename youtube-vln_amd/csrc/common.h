@@ -145,6 +145,25 @@ __device__ __forceinline__ float dgelu_erf(float x) {
     return cdf + x * pdf;
 }
 
+// The same two functions for the bf16-RESIDENT path, whose every result is rounded to bf16 (8 significant bits) on its way out: Phi(x) by
+// Abramowitz-Stegun 7.1.26 -- |error| < 6e-7 in fp32 arithmetic against the exact function (checked over [-12, 12], four orders under the
+// rounding that follows), branch-free: one v_rcp, one v_exp, six fma.  The library's erff is two polynomial branches that a wave with mixed
+// arguments runs both of (~50 vector instructions per value): on 129024 x 1024 outputs that was 170 us of a 445 us launch
+// (profiles/round6_gemm_bf16_epilogues.log).  The fp32 path keeps erff: it owes the reference 1e-4 on logits, not 4e-3.
+__device__ __forceinline__ float phi_as(float x, float& e) {          // Phi(x); e = exp(-x^2 / 2) for the density
+    const float az = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    e = __expf(-az * az);
+    const float h = 0.5f * (p * t) * e;          // = 0.5 erfc(|x| / sqrt 2): the small side, no cancellation for negative x
+    return x < 0.f ? h : 1.0f - h;
+}
+__device__ __forceinline__ float gelu_erf_b(float x) { float e; return x * phi_as(x, e); }
+__device__ __forceinline__ float dgelu_erf_b(float x) { float e; const float cdf = phi_as(x, e); return fmaf(x * 0.39894228040143267794f, e, cdf); }
+
 // ---- memory operations of the interior epilogue, written out: scalar row base + one 32-bit per-lane byte offset -------------------------------
 // (hipcc turns the C++ form of "uniform pointer + per-lane offset" into 64-bit per-lane address arithmetic or, through integer casts, into FLAT
 // accesses; the saddr form needs no address registers at all.)  Loads issued this way are invisible to the compiler's s_waitcnt insertion:
